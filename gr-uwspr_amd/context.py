@@ -1,0 +1,253 @@
+"""Thin Python handle on a uwspr_ctx (include/uwspr_hip.h) for tests and bench.
+
+Arrays in, arrays out; every number comes from the HIP library.  Frames may be
+numpy arrays (host path: staged by the library) or torch CUDA tensors (device
+path: pointers are passed through untouched).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import native as N
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
+
+
+class Context:
+    """Parameters mirror gr::uwspr::FDR::make / sync_and_demodulate::make
+    (include/uwspr/FDR.h:49-50, include/uwspr/sync_and_demodulate.h:49)."""
+
+    def __init__(self, fs=375, fl=45000, spb=256, maxdrift=0, maxfreqs=200, halfbandwidth=10,
+                 cf=1500, threshold=10, device=0):
+        self.L = N.lib()
+        self.params = N.Params(fs, fl, spb, maxdrift, maxfreqs, halfbandwidth, cf, threshold)
+        self.h = C.c_void_p()
+        rc = self.L.uwspr_ctx_create(C.byref(self.params), device, C.byref(self.h))
+        if rc != 0:
+            msg = self.L.uwspr_last_error(self.h).decode() if self.h else \
+                self.L.uwspr_status_string(rc).decode()
+            if self.h:
+                self.L.uwspr_ctx_destroy(self.h)
+                self.h = C.c_void_p()
+            raise N.UwsprError(rc, msg)
+        self.info = N.Info()
+        self._chk(self.L.uwspr_get_info(self.h, C.byref(self.info)))
+        self.fl, self.maxfreqs = fl, maxfreqs
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.uwspr_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise N.UwsprError(rc, self.L.uwspr_last_error(self.h).decode())
+
+    # -- helpers -----------------------------------------------------------
+    def _frames(self, frames):
+        """-> (pointer, B, where, keepalive)"""
+        if _is_torch(frames):
+            assert frames.is_cuda and frames.is_contiguous() and frames.dtype.is_floating_point
+            assert frames.element_size() == 4
+            B = frames.numel() // (2 * self.fl)
+            return C.c_void_p(frames.data_ptr()), B, N.DEVICE, frames
+        a = np.ascontiguousarray(frames, dtype=np.float32).reshape(-1, self.fl, 2)
+        return C.c_void_p(a.ctypes.data), a.shape[0], N.HOST, a
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.uwspr_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._chk(self.L.uwspr_synchronize(self.h))
+
+    # -- FDR ---------------------------------------------------------------
+    def fdr_batch(self, frames):
+        """-> list (per frame) of candidate record arrays, FDR_impl.cc:214-456."""
+        p, B, where, keep = self._frames(frames)
+        if where == N.DEVICE:
+            import torch
+            cands = torch.empty(B * self.maxfreqs * 48, dtype=torch.uint8, device=frames.device)
+            npk = torch.empty(B, dtype=torch.int32, device=frames.device)
+            self._chk(self.L.uwspr_fdr_batch(self.h, p, B, where, C.c_void_p(cands.data_ptr()),
+                                             C.c_void_p(npk.data_ptr())))
+            self.synchronize()
+            cands = np.frombuffer(cands.cpu().numpy().tobytes(), N.CAND_DTYPE).reshape(B, -1)
+            npk = npk.cpu().numpy()
+        else:
+            cands = np.zeros((B, self.maxfreqs), N.CAND_DTYPE)
+            npk = np.zeros(B, np.int32)
+            self._chk(self.L.uwspr_fdr_batch(self.h, p, B, where, C.c_void_p(cands.ctypes.data),
+                                             C.c_void_p(npk.ctypes.data)))
+        return [cands[b, :npk[b]].copy() for b in range(B)]
+
+    def fdr_spectrum(self, B):
+        i = self.info
+        ps = np.empty((B, i.n, i.band_w), np.float32)
+        psavg = np.empty((B, i.band_w), np.float32)
+        smraw = np.empty((B, i.finpb), np.float32)
+        smspec = np.empty((B, i.finpb), np.float32)
+        noise = np.empty(B, np.float32)
+        self._chk(self.L.uwspr_fdr_read_spectrum(self.h, B, *[C.c_void_p(a.ctypes.data) for a in
+                                                              (ps, psavg, smraw, smspec, noise)]))
+        return ps, psavg, smraw, smspec, noise
+
+    def keep_syncgrid(self, ncand_cap):
+        self._chk(self.L.uwspr_fdr_keep_syncgrid(self.h, ncand_cap))
+        self._grid_cap = ncand_cap
+
+    def fdr_syncgrid(self, B):
+        g = np.empty((B, self._grid_cap, N.NIFR, N.NK0, self.info.cell_hyps), np.float32)
+        self._chk(self.L.uwspr_fdr_read_syncgrid(self.h, B, C.c_void_p(g.ctypes.data)))
+        return g
+
+    # -- fine sweep --------------------------------------------------------
+    def sync_sweep(self, frames, hyps, soft=True):
+        """hyps: HYP_DTYPE array. -> (sync[H], symbols[H,162] or None)."""
+        p, B, where, keep = self._frames(frames)
+        hyps = np.ascontiguousarray(hyps, dtype=N.HYP_DTYPE)
+        H = hyps.size
+        if where == N.DEVICE:
+            import torch
+            dh = torch.from_numpy(np.frombuffer(hyps.tobytes(), np.uint8).copy()).to(frames.device)
+            sync = torch.empty(H, dtype=torch.float32, device=frames.device)
+            sym = torch.empty(H * N.NSYM, dtype=torch.uint8, device=frames.device) if soft else None
+            self._chk(self.L.uwspr_sync_sweep(self.h, p, B, C.c_void_p(dh.data_ptr()), H, where,
+                                              C.c_void_p(sync.data_ptr()),
+                                              C.c_void_p(sym.data_ptr()) if soft else None))
+            self.synchronize()
+            return sync.cpu().numpy(), (sym.cpu().numpy().reshape(H, N.NSYM) if soft else None)
+        sync = np.empty(H, np.float32)
+        sym = np.empty((H, N.NSYM), np.uint8) if soft else None
+        self._chk(self.L.uwspr_sync_sweep(self.h, p, B, C.c_void_p(hyps.ctypes.data), H, where,
+                                          C.c_void_p(sync.ctypes.data),
+                                          C.c_void_p(sym.ctypes.data) if soft else None))
+        return sync, sym
+
+    def sync_and_demodulate(self, frames, calls):
+        """calls: CALL_DTYPE array, one per sync_and_demodulate() invocation
+        (sync_and_demodulate_impl.cc:126-131). -> RESULT_DTYPE array."""
+        p, B, where, keep = self._frames(frames)
+        calls = np.ascontiguousarray(calls, dtype=N.CALL_DTYPE)
+        res = np.zeros(calls.size, N.RESULT_DTYPE)
+        self._chk(self.L.uwspr_sync_and_demodulate_batch(self.h, p, B, where,
+                                                         C.c_void_p(calls.ctypes.data), calls.size,
+                                                         C.c_void_p(res.ctypes.data)))
+        return res
+
+    # -- schedule ----------------------------------------------------------
+    def demod_batch(self, frames, cands_per_frame, max_per_frame=1):
+        p, B, where, keep = self._frames(frames)
+        assert where == N.HOST, "demod_batch with device frames: use pipeline_batch"
+        stride = max(1, max(len(c) for c in cands_per_frame))
+        cands = np.zeros((B, stride), N.CAND_DTYPE)
+        npk = np.zeros(B, np.int32)
+        for b, c in enumerate(cands_per_frame):
+            cands[b, :len(c)] = c
+            npk[b] = len(c)
+        out = np.zeros((B, max_per_frame), N.DEMOD_DTYPE)
+        self._chk(self.L.uwspr_demod_batch(self.h, p, B, where, C.c_void_p(cands.ctypes.data),
+                                           C.c_void_p(npk.ctypes.data), stride, max_per_frame,
+                                           C.c_void_p(out.ctypes.data)))
+        return out
+
+    def pipeline_batch(self, frames, max_per_frame=1, fetch=True):
+        """FDR + refinement schedule. -> (cands list, demod_out[B,max_per_frame]) or None."""
+        p, B, where, keep = self._frames(frames)
+        if where == N.DEVICE:
+            import torch
+            if not fetch:
+                self._chk(self.L.uwspr_pipeline_batch(self.h, p, B, where, max_per_frame, None,
+                                                      None, None))
+                return None
+            dev = frames.device
+            cands = torch.empty(B * self.maxfreqs * 48, dtype=torch.uint8, device=dev)
+            npk = torch.empty(B, dtype=torch.int32, device=dev)
+            out = torch.empty(B * max_per_frame * N.DEMOD_DTYPE.itemsize, dtype=torch.uint8,
+                              device=dev)
+            self._chk(self.L.uwspr_pipeline_batch(self.h, p, B, where, max_per_frame,
+                                                  C.c_void_p(cands.data_ptr()),
+                                                  C.c_void_p(npk.data_ptr()),
+                                                  C.c_void_p(out.data_ptr())))
+            self.synchronize()
+            cands = np.frombuffer(cands.cpu().numpy().tobytes(), N.CAND_DTYPE).reshape(B, -1)
+            npk = npk.cpu().numpy()
+            out = np.frombuffer(out.cpu().numpy().tobytes(), N.DEMOD_DTYPE).reshape(B, -1)
+        else:
+            cands = np.zeros((B, self.maxfreqs), N.CAND_DTYPE)
+            npk = np.zeros(B, np.int32)
+            out = np.zeros((B, max_per_frame), N.DEMOD_DTYPE)
+            self._chk(self.L.uwspr_pipeline_batch(self.h, p, B, where, max_per_frame,
+                                                  C.c_void_p(cands.ctypes.data),
+                                                  C.c_void_p(npk.ctypes.data),
+                                                  C.c_void_p(out.ctypes.data)))
+        return [cands[b, :npk[b]].copy() for b in range(B)], out.copy()
+
+    # -- measurement -------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._chk(self.L.uwspr_prof_enable(self.h, 1 if on else 0))
+
+    def prof_read(self):
+        p = N.Prof()
+        self._chk(self.L.uwspr_prof_read(self.h, C.byref(p)))
+        return {k: {"ms": p.ms[i], "launches": p.launches[i], "units": p.units[i]}
+                for i, k in enumerate(N.K_NAMES)}
+
+
+# ---- host tail (no device needed) -------------------------------------------
+def deinterleave(symbols):
+    s = np.array(symbols, dtype=np.uint8).copy()
+    N.lib().uwspr_deinterleave(C.c_void_p(s.ctypes.data))
+    return s
+
+
+def fano_decode(symbols, delta=60, maxcycles=10000):
+    s = np.ascontiguousarray(symbols, dtype=np.uint8)
+    data = np.zeros(11, np.uint8)
+    metric, cycles, maxnp = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = N.lib().uwspr_fano_decode(C.c_void_p(s.ctypes.data), C.c_void_p(data.ctypes.data),
+                                   C.byref(metric), C.byref(cycles), C.byref(maxnp), delta,
+                                   maxcycles)
+    return rc, data, metric.value, cycles.value
+
+
+def fano_encode(data_bytes):
+    d = np.ascontiguousarray(data_bytes, dtype=np.uint8)
+    out = np.zeros(d.size * 16, np.uint8)
+    N.lib().uwspr_fano_encode(C.c_void_p(out.ctypes.data), C.c_void_p(d.ctypes.data), d.size)
+    return out
+
+
+def decode_candidate(demod_rec):
+    """demod_rec: one DEMOD_DTYPE record. -> (message7 int8 array, idt) or None."""
+    rec = np.ascontiguousarray(np.array(demod_rec, dtype=N.DEMOD_DTYPE).reshape(1))
+    msg = np.zeros(7, np.int8)
+    idt = C.c_int32(-1)
+    ok = N.lib().uwspr_decode_candidate(C.c_void_p(rec.ctypes.data), C.c_void_p(msg.ctypes.data),
+                                        C.byref(idt))
+    return (msg, idt.value) if ok else None
+
+
+def unpack_message(message7):
+    m = np.ascontiguousarray(message7, dtype=np.int8)
+    buf = C.create_string_buffer(32)
+    rc = N.lib().uwspr_unpack_message(C.c_void_p(m.ctypes.data), buf, 32)
+    return rc, buf.value.decode("ascii", "replace")
+
+
+def c2_read(path):
+    iq = np.zeros((45000, 2), np.float32)
+    freq, typ = C.c_double(), C.c_int32()
+    rc = N.lib().uwspr_c2_read(path.encode(), C.c_void_p(iq.ctypes.data), C.byref(freq),
+                               C.byref(typ))
+    if rc != 0:
+        raise N.UwsprError(rc, "cannot read %s" % path)
+    return iq, freq.value, typ.value

@@ -1,0 +1,114 @@
+// fft512_lane.h -- per-lane arithmetic of the 512-point spectrogram FFT (K1).
+//
+// One 64-lane wavefront transforms one 512-sample row; every lane owns 8
+// complex points and runs three register-resident radix-8 passes, each of
+// which is three fused radix-2 decimation-in-time stages.  The arithmetic is
+// the textbook iterative radix-2 DIT FFT on bit-reversed input
+//     t = W*x[b+j+h];  x[b+j] = u + t;  x[b+j+h] = u - t
+// stage for stage and butterfly for butterfly, only re-associated across lanes,
+// so results are bit-identical to a scalar radix-2 DIT using the same twiddle
+// table (binary32, no FMA contraction).  The reference computes this with
+// FFTW3f (lib/FDR_impl.cc:123-132,244), a third-party library whose rounding
+// is unpinned.
+//
+// Index algebra (p = position in the bit-reversed array, 9 bits):
+//   pass A (h=1,2,4):    lane L holds p = 8*rev6(L) + r,      r = 0..7
+//   pass B (h=8,16,32):  lane L holds p = 64*(L>>3) + 8*b + (L&7), b = 0..7
+//   pass C (h=64..256):  lane L holds p = 64*a + L,           a = 0..7
+// Functions are host+device so the lane algebra can be unit-tested by
+// emulating the 64 lanes on the CPU (tests/host_emul).
+#pragma once
+
+#ifdef __HIPCC__
+#define UWSPR_HD __host__ __device__ __forceinline__
+#else
+#define UWSPR_HD inline
+#endif
+
+namespace uwspr {
+
+struct cpx { float r, i; };
+
+UWSPR_HD int rev3(int x) { return ((x & 1) << 2) | (x & 2) | ((x >> 2) & 1); }
+UWSPR_HD int rev6(int x) { return (rev3(x & 7) << 3) | rev3((x >> 3) & 7); }
+
+// LDS image index of position p used by both exchanges (pad 1 per 32 to
+// spread the strided accesses over banks).
+UWSPR_HD int xidx(int p) { return p + (p >> 5); }
+constexpr int XCHG_LEN = 512 + 16;
+
+// u,v <- u + w*v, u - w*v   (general twiddle)
+UWSPR_HD void bfly(cpx &u, cpx &v, float wr, float wi) {
+  float tr = wr * v.r - wi * v.i;
+  float ti = wr * v.i + wi * v.r;
+  float ur = u.r, ui = u.i;
+  u.r = ur + tr; u.i = ui + ti;
+  v.r = ur - tr; v.i = ui - ti;
+}
+// w = 1
+UWSPR_HD void bfly1(cpx &u, cpx &v) {
+  float tr = v.r, ti = v.i, ur = u.r, ui = u.i;
+  u.r = ur + tr; u.i = ui + ti;
+  v.r = ur - tr; v.i = ui - ti;
+}
+// w = -i :  t = (v.i, -v.r)
+UWSPR_HD void bflymi(cpx &u, cpx &v) {
+  float tr = v.i, ti = -v.r, ur = u.r, ui = u.i;
+  u.r = ur + tr; u.i = ui + ti;
+  v.r = ur - tr; v.i = ui - ti;
+}
+
+// Twiddles one lane needs for one radix-8 pass: 1 for the first fused stage,
+// 2 for the second, 4 for the third.
+struct pass_tw { cpx s1, s2[2], s3[4]; };
+
+// tw = table [256] of (cos, -sin)(2*pi*k/512).  unit = the lane's j offset
+// (r for pass B, c for pass C); hs = first half-size of the pass (8 or 64).
+UWSPR_HD pass_tw load_pass_tw(const cpx *tw, int unit, int hs) {
+  pass_tw t;
+  t.s1 = tw[unit * (256 / hs)];
+#pragma unroll
+  for (int e = 0; e < 2; e++) t.s2[e] = tw[(hs * e + unit) * (256 / (2 * hs))];
+#pragma unroll
+  for (int e = 0; e < 4; e++) t.s3[e] = tw[(hs * e + unit) * (256 / (4 * hs))];
+  return t;
+}
+
+// Pass A: registers y[r] hold positions 8q+r.  Twiddles are the constants
+// tw[0]=1, tw[128]=-i, tw[64], tw[192].
+UWSPR_HD void pass_a(cpx y[8], cpx w64, cpx w192) {
+  bfly1(y[0], y[1]); bfly1(y[2], y[3]); bfly1(y[4], y[5]); bfly1(y[6], y[7]);
+  bfly1(y[0], y[2]); bflymi(y[1], y[3]); bfly1(y[4], y[6]); bflymi(y[5], y[7]);
+  bfly1(y[0], y[4]);
+  bfly(y[1], y[5], w64.r, w64.i);
+  bflymi(y[2], y[6]);
+  bfly(y[3], y[7], w192.r, w192.i);
+}
+
+// Pass B / C: registers v[e], e = 0..7 = the 3 bits being combined.
+UWSPR_HD void pass_bc(cpx v[8], const pass_tw &t) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) bfly(v[e], v[e + 1], t.s1.r, t.s1.i);
+#pragma unroll
+  for (int g = 0; g < 8; g += 4) {
+    bfly(v[g + 0], v[g + 2], t.s2[0].r, t.s2[0].i);
+    bfly(v[g + 1], v[g + 3], t.s2[1].r, t.s2[1].i);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; e++) bfly(v[e], v[e + 4], t.s3[e].r, t.s3[e].i);
+}
+
+// Which input sample (0..511) lane L keeps in register slot r before pass A:
+// position p = 8*rev6(L)+r holds x[rev9(p)] = x[L + 64*rev3(r)].
+UWSPR_HD int in_sample(int L, int r) { return L + 64 * rev3(r); }
+// exchange 1: lane L writes slot r to position...
+UWSPR_HD int posA(int L, int r) { return 8 * rev6(L) + r; }
+// ...and lane L reads slot b for pass B from position
+UWSPR_HD int posB(int L, int b) { return 64 * (L >> 3) + 8 * b + (L & 7); }
+// exchange 2: lane L reads slot a for pass C from position
+UWSPR_HD int posC(int L, int a) { return 64 * a + L; }
+// after pass C lane L slot a holds DFT bin k = 64a+L; fftshifted column
+// (FDR_impl.cc:247-248: ps[i][j] = |X[(j+spb) mod size]|^2) is j = k ^ 256.
+UWSPR_HD int out_col(int L, int a) { return (64 * a + L) ^ 256; }
+
+}  // namespace uwspr

@@ -1,0 +1,122 @@
+// K2 -- average spectrum, smoothing, noise percentile, normalisation, peak
+// pick and candidate sort: FDR_impl::transform, lib/FDR_impl.cc:257-319.
+//
+// Tiny (per frame: 348 x band_w adds, then <= 512-element vectors); one
+// 256-thread workgroup per frame.  Every reduction keeps the reference's
+// left-to-right binary32 order:
+//   psavg[j]  = sum over rows i ascending            (cc:257-263)
+//   smspec[i] = sum over j=-3..3 ascending           (cc:268-275)
+// The qsort + percentile (cc:277-285) is a rank selection (any correct sort
+// yields the same value), the peak scan (cc:293-306) is an ordered compaction,
+// the bubble sort (cc:311-319) is a stable descending rank by snr.
+#include "uwspr_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace uwspr {
+
+constexpr int K2_THREADS = 256;
+constexpr int K2_MAXV = 512;  // >= band_w and >= finpb
+
+__global__ __launch_bounds__(K2_THREADS) void k2_spectrum(
+    const float *__restrict__ ps, fdr_consts f, float *__restrict__ psavg_g,
+    float *__restrict__ smraw_g, float *__restrict__ smspec_g, float *__restrict__ noise_g,
+    uwspr_candidate *__restrict__ cands, int32_t *__restrict__ npk_g) {
+  __shared__ float psavg[K2_MAXV];
+  __shared__ float sm[K2_MAXV];
+  __shared__ int flag[K2_MAXV];
+  __shared__ float pk_freq[K2_MAXV / 2 + 1];
+  __shared__ float pk_snr[K2_MAXV / 2 + 1];
+  __shared__ float noise_s;
+  __shared__ int npk_s;
+
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *psb = ps + (size_t)b * f.n * f.band_w;
+  if (tid == 0) noise_s = __builtin_nanf("");  // stays NaN only if the frame holds NaNs
+
+  // psavg over the kept columns, rows ascending (cc:257-263)
+  for (int col = tid; col < f.band_w; col += K2_THREADS) {
+    float acc = 0.0f;
+    for (int i = 0; i < f.n; i++) acc = acc + psb[(size_t)i * f.band_w + col];
+    psavg[col] = acc;
+    psavg_g[(size_t)b * f.band_w + col] = acc;
+  }
+  __syncthreads();
+
+  // 7-tap smoothing inside the pass band (cc:265-275)
+  for (int i = tid; i < f.finpb; i += K2_THREADS) {
+    float acc = 0.0f;
+    for (int j = -3; j <= 3; j++) acc = acc + psavg[f.m - f.hpbm + i + j - f.band_lo];
+    sm[i] = acc;
+    smraw_g[(size_t)b * f.finpb + i] = acc;
+  }
+  __syncthreads();
+
+  // 30th percentile by rank selection (cc:277-285)
+  for (int i = tid; i < f.finpb; i += K2_THREADS) {
+    float v = sm[i];
+    int rank = 0;
+    for (int j = 0; j < f.finpb; j++) {
+      float u = sm[j];
+      rank += (u < v) || (u == v && j < i);
+    }
+    if (rank == f.noiseidx) noise_s = v;
+  }
+  if (tid == 0) npk_s = 0;
+  __syncthreads();
+  const float noise = noise_s;
+  if (tid == 0) noise_g[b] = noise;
+
+  // SNR in linear form and floor (cc:287-291)
+  for (int j = tid; j < f.finpb; j += K2_THREADS) {
+    float v = (float)((double)__fdiv_rn(sm[j], noise) - 1.0);
+    if (v < f.min_snr) v = f.min_snr_floor;
+    sm[j] = v;   // each thread rewrites only its own slots
+    smspec_g[(size_t)b * f.finpb + j] = v;
+  }
+  __syncthreads();
+
+  // strict local maxima (cc:293-306)
+  for (int j = tid; j < f.finpb; j += K2_THREADS)
+    flag[j] = (j >= 1 && j < f.finpb - 1 && sm[j] > sm[j - 1] && sm[j] > sm[j + 1]) ? 1 : 0;
+  __syncthreads();
+  for (int j = tid; j < f.finpb; j += K2_THREADS) {
+    if (flag[j]) {
+      int pos = 0;
+      for (int q = 0; q < j; q++) pos += flag[q];
+      if (pos < f.maxfreqs) {
+        pk_freq[pos] = (float)(j - f.hpbm) * f.df;
+        // cc:303: 10*log10(smspec) as a binary32 value
+        pk_snr[pos] = 10.0f * (float)log10((double)sm[j]);
+        atomicAdd(&npk_s, 1);
+      }
+    }
+  }
+  __syncthreads();
+  const int npk = npk_s;
+  if (tid == 0) npk_g[b] = npk;
+
+  // stable descending order by snr (bubble sort cc:309-319)
+  uwspr_candidate *out = cands + (size_t)b * f.maxfreqs;
+  for (int k = tid; k < npk; k += K2_THREADS) {
+    float s = pk_snr[k];
+    int rank = 0;
+    for (int q = 0; q < npk; q++) {
+      float u = pk_snr[q];
+      rank += (u > s) || (u == s && q < k);
+    }
+    uwspr_candidate c;
+    c.freq = pk_freq[k]; c.snr = s; c.drift = 0.0f; c.sync = 0.0f; c.shift = 0;
+    c.m_type = UWSPR_LINEAR;
+    c.m_nonlinear.V1 = 0.0; c.m_nonlinear.V2 = 0.0; c.m_nonlinear.p1 = 0; c.m_nonlinear.p2 = 0;
+    out[rank] = c;
+  }
+}
+
+void launch_spectrum(uwspr_ctx *c, int B) {
+  prof_scope ps(c, UWSPR_K_SPECTRUM, B);
+  hipLaunchKernelGGL(k2_spectrum, dim3(B), dim3(K2_THREADS), 0, c->stream, c->d_ps, c->fc,
+                     c->d_psavg, c->d_smraw, c->d_smspec, c->d_noise, c->d_cands, c->d_npk);
+}
+
+}  // namespace uwspr

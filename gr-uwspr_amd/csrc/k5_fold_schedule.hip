@@ -1,0 +1,287 @@
+// K5 -- per-hypothesis fold of the 162x4 tone magnitudes into the sync metric
+// and the soft symbols, plus the tiny kernels that chain the refinement
+// schedule stage to stage entirely in HBM.
+//
+// Reference:
+//   fold           sync_and_demodulate_impl.cc:213-226 (totp, cmet, ss, ss/totp)
+//   soft symbols   cc:216-224 and the mode-2 epilogue cc:240-254
+//   schedule       sync_and_demodulate_impl::demodulate cc:403-482 (S0..S5)
+//   best-of rule   cc:227-231 (strict >, first wins; -1e30 / 0 / 0.0 defaults)
+#include "uwspr_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace uwspr {
+
+__device__ __constant__ uint32_t kPr3[6] = UWSPR_PR3_WORDS;
+__device__ __forceinline__ bool pr3_rt(int i) { return (kPr3[i >> 5] >> (i & 31)) & 1u; }
+
+// ------------------------------------------------------------------- K5 fold
+// One lane per hypothesis, 162 sequential steps in symbol order: the
+// reference's accumulation order for totp / ss / fsum / f2sum.
+__global__ __launch_bounds__(256) void k5_fold(const dev_hyp *__restrict__ hyps,
+                                               const float4 *__restrict__ p, int H,
+                                               float symfac, float *__restrict__ sync,
+                                               uint8_t *__restrict__ symbols) {
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  if (h >= H) return;
+  const float4 *ph = p + (size_t)h * UWSPR_NSYM;
+  if (hyps[h].frame < 0) {
+    sync[h] = -1e30f;
+    if (symbols)
+      for (int i = 0; i < UWSPR_NSYM; i++) symbols[(size_t)h * UWSPR_NSYM + i] = 0;
+    return;
+  }
+  float ss = 0.0f, totp = 0.0f, fsum = 0.0f, f2sum = 0.0f;
+  const bool soft = symbols != nullptr;
+#pragma unroll 6
+  for (int i = 0; i < UWSPR_NSYM; i++) {
+    const float4 P = ph[i];
+    const bool bit = pr3_rt(i);
+    totp = totp + P.x; totp = totp + P.y; totp = totp + P.z; totp = totp + P.w;  // cc:213
+    const float cmet = (P.y + P.w) - (P.x + P.z);                               // cc:214
+    ss = bit ? ss + cmet : ss - cmet;                                           // cc:215
+    if (soft) {
+      const float fs = bit ? P.w - P.y : P.z - P.x;                             // cc:219,222
+      fsum = (float)((double)fsum + (double)fs / 162.0);                        // cc:243
+      f2sum = (float)((double)f2sum + (double)(fs * fs) / 162.0);               // cc:244
+    }
+  }
+  sync[h] = __fdiv_rn(ss, totp);  // cc:226
+  if (soft) {
+    const float fac = __fsqrt_rn(f2sum - fsum * fsum);  // cc:246
+    uint8_t *out = symbols + (size_t)h * UWSPR_NSYM;
+    for (int i = 0; i < UWSPR_NSYM; i++) {
+      const float4 P = ph[i];
+      const bool bit = pr3_rt(i);
+      float v = bit ? P.w - P.y : P.z - P.x;
+      v = __fdiv_rn(symfac * v, fac);  // cc:248
+      if (v > 127.0f) v = 127.0f;
+      if (v < -128.0f) v = -128.0f;
+      v = v + 128.0f;
+      out[i] = (v != v) ? (uint8_t)0 : (uint8_t)(int)v;  // cc:251 (NaN defined as 0)
+    }
+  }
+}
+
+void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, float *sync,
+                 uint8_t *symbols) {
+  if (H <= 0) return;
+  prof_scope ps(c, UWSPR_K_FOLD, H);
+  hipLaunchKernelGGL(k5_fold, dim3((H + 255) / 256), dim3(256), 0, c->stream, hyps, p, H, 50.0f,
+                     sync, symbols);
+}
+
+// ----------------------------------------------------- ABI hyp -> device hyp
+// slmFrequencyDrift(m_nl, cf, t = 0), lib/slm.cc:36-73, in binary64 like the
+// reference.  (`t` is read uninitialised at sync_and_demodulate_impl.cc:177-180;
+// every observed build behaves as t = 0)
+__device__ float slm_drift_t0(double V1, double V2, int p1, int p2, float cf) {
+  const double q1 = V1 * 0.0 + (double)p1, q2 = V2 * 0.0 + (double)p2;
+  const float sign = (float)(((q1 * V1 + q2 * V2) > 0) * 2 - 1);
+  const double num = fabs(V1 * q1 + V2 * q2);
+  const double den = sqrt(q1 * q1 + q2 * q2);
+  if (den == 0) return 0.0f;
+  return (float)((double)(-sign) * num / den * (double)cf / (double)1500.0f);
+}
+
+__global__ void k_prep_hyps(const uwspr_hyp *__restrict__ in, dev_hyp *__restrict__ out, int H,
+                            float cf) {
+  const int h = blockIdx.x * 256 + threadIdx.x;
+  if (h >= H) return;
+  const uwspr_hyp a = in[h];
+  dev_hyp d;
+  d.frame = a.frame; d.lag = a.lag; d.f0 = a.f0; d.drift = a.drift; d.m_type = a.m_type;
+  d.slmc = (a.m_type == UWSPR_NONLINEAR) ? slm_drift_t0(a.V1, a.V2, a.p1, a.p2, cf) : 0.0f;
+  out[h] = d;
+}
+
+void launch_prep_hyps(uwspr_ctx *c, const uwspr_hyp *abi, dev_hyp *out, int H) {
+  if (H <= 0) return;
+  prof_scope ps(c, UWSPR_K_SCHED, H);
+  hipLaunchKernelGGL(k_prep_hyps, dim3((H + 255) / 256), dim3(256), 0, c->stream, abi, out, H,
+                     (float)c->p.cf);
+}
+
+// ------------------------------------------------------------ the schedule
+// Stage s consumes the metrics of the hypotheses stage s-1 generated and
+// emits the next ones; hypotheses per candidate: S0 5, S1 5, S2 2, S3 5, S4 5,
+// S5 17 (cc:409-482).  One thread per candidate slot.
+__device__ __constant__ int kHpc[6] = {5, 5, 2, 5, 5, 17};
+
+__device__ inline void emit(dev_hyp *h, const cand_state &st, bool on, int lag, float f0,
+                            float drift) {
+  h->frame = on ? st.frame : -1;
+  h->lag = lag; h->f0 = f0; h->drift = drift; h->slmc = st.slmc; h->m_type = st.m_type;
+}
+
+// cc:227-231 over a list scanned in order: strict >, defaults -1e30 / 0 / 0.0
+struct best3 { float sync; int shift; float f; };
+__device__ inline best3 best_of(const float *sy, const dev_hyp *hy, int n) {
+  best3 b{-1e30f, 0, 0.0f};
+  for (int q = 0; q < n; q++)
+    if (sy[q] > b.sync) { b.sync = sy[q]; b.shift = hy[q].lag; b.f = hy[q].f0; }
+  return b;
+}
+
+__global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
+                             const int32_t *__restrict__ npk, int cand_stride, int B,
+                             int per_frame, float cf, cand_state *__restrict__ state,
+                             dev_hyp *__restrict__ hyps) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot >= B * per_frame) return;
+  const int b = slot / per_frame, j = slot - b * per_frame;
+  cand_state st;
+  const bool on = j < npk[b] && j < cand_stride;
+  if (on) {
+    const uwspr_candidate cnd = cands[(size_t)b * cand_stride + j];
+    st.frame = b;
+    st.m_type = cnd.m_type;
+    st.slmc = (cnd.m_type == UWSPR_NONLINEAR)
+                  ? slm_drift_t0(cnd.m_nonlinear.V1, cnd.m_nonlinear.V2, cnd.m_nonlinear.p1,
+                                 cnd.m_nonlinear.p2, cf)
+                  : 0.0f;
+    st.f1 = cnd.freq;                                               // cc:404
+    st.drift1 = (cnd.m_type == UWSPR_LINEAR) ? cnd.m_linear.drift : 0.0f;  // cc:405,373
+    st.shift1 = cnd.shift;                                          // cc:406
+    st.sync1 = cnd.sync;                                            // cc:407
+  } else {
+    st.frame = -1; st.m_type = 0; st.slmc = 0.0f; st.f1 = 0.0f; st.drift1 = 0.0f;
+    st.shift1 = 0; st.sync1 = 0.0f;
+  }
+  st.worth = 0; st.driftp = 0.0f; st.driftm = 0.0f;
+  state[slot] = st;
+  // S0 (cc:409-415): mode 0, lag = shift1-128 .. shift1+128 step 64, f0 = f1 + 0*0.0f
+  dev_hyp *h = hyps + (size_t)slot * 5;
+  const float f0 = st.f1 + (float)0 * 0.0f;
+  for (int q = 0; q < 5; q++) emit(&h[q], st, on, st.shift1 - 128 + 64 * q, f0, st.drift1);
+}
+
+template <int STAGE>
+__global__ void k_sched_step(cand_state *__restrict__ state, const dev_hyp *__restrict__ hin,
+                             const float *__restrict__ sync, dev_hyp *__restrict__ hout,
+                             int nslots) {
+  const int slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot >= nslots) return;
+  cand_state st = state[slot];
+  const bool live = st.frame >= 0;
+  constexpr int NIN = STAGE == 1 ? 5 : STAGE == 2 ? 5 : STAGE == 3 ? 2 : STAGE == 4 ? 5 : 5;
+  constexpr int NOUT = STAGE == 1 ? 5 : STAGE == 2 ? 2 : STAGE == 3 ? 5 : STAGE == 4 ? 5 : 17;
+  const dev_hyp *hi = hin + (size_t)slot * NIN;
+  const float *sy = sync + (size_t)slot * NIN;
+  dev_hyp *ho = hout + (size_t)slot * NOUT;
+
+  if (STAGE == 1) {
+    // after S0 (mode 0) -> S1 (cc:416-419): mode 1, f = f1 + ifreq*0.25, lag = shift1
+    if (live) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
+    for (int q = 0; q < 5; q++)
+      emit(&ho[q], st, live, st.shift1, st.f1 + (float)(q - 2) * 0.25f, st.drift1);
+  } else if (STAGE == 2) {
+    // after S1 -> S2 (cc:423-433): linear only, drift1 +- 0.5 at (f1, shift1)
+    if (live) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
+    const bool lin = live && st.m_type == UWSPR_LINEAR;
+    st.driftp = (float)((double)st.drift1 + 0.5);
+    st.driftm = (float)((double)st.drift1 - 0.5);
+    const float f0 = st.f1 + (float)0 * 0.0f;
+    emit(&ho[0], st, lin, st.shift1, f0, st.driftp);
+    emit(&ho[1], st, lin, st.shift1, f0, st.driftm);
+  } else if (STAGE == 3) {
+    // after S2 (cc:434-441), gate (cc:443) -> S3 (cc:444-447): lag = shift1-32..+32 step 16
+    if (live && st.m_type == UWSPR_LINEAR) {
+      // each mode-1 call writes *f1/*shift1 back (cc:236-237): unchanged unless
+      // its metric failed to beat -1e30 (NaN), where the defaults 0 / 0.0 land
+      float syncp = -1e30f, syncm = -1e30f;
+      if (sy[0] > syncp) syncp = sy[0]; else { st.f1 = 0.0f; st.shift1 = 0; }
+      if (sy[1] > syncm) syncm = sy[1]; else { st.f1 = 0.0f; st.shift1 = 0; }
+      if (syncp > st.sync1) { st.drift1 = st.driftp; st.sync1 = syncp; }
+      else if (syncm > st.sync1) { st.drift1 = st.driftm; st.sync1 = syncm; }
+    }
+    st.worth = (live && st.sync1 > 0.10f) ? 1 : 0;
+    const float f0 = st.f1 + (float)0 * 0.0f;
+    for (int q = 0; q < 5; q++)
+      emit(&ho[q], st, st.worth != 0, st.shift1 - 32 + 16 * q, f0, st.drift1);
+  } else if (STAGE == 4) {
+    // after S3 -> S4 (cc:449-452): f = f1 + ifreq*0.05
+    if (st.worth) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
+    for (int q = 0; q < 5; q++)
+      emit(&ho[q], st, st.worth != 0, st.shift1, st.f1 + (float)(q - 2) * 0.05f, st.drift1);
+  } else {
+    // after S4 -> S5 (cc:457-468): 17 jiggered shifts, mode 2
+    if (st.worth) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
+    for (int idt = 0; idt < UWSPR_NJIG; idt++) {
+      int ii = (idt + 1) / 2;
+      if (idt % 2 == 1) ii = -ii;
+      ii = 8 * ii;
+      emit(&ho[idt], st, st.worth != 0, st.shift1 + ii, st.f1, st.drift1);
+    }
+  }
+  state[slot] = st;
+}
+
+// out[slot]: state + per-try sync / rms / shift / symbols (cc:465-475)
+__global__ void k_sched_finish(const cand_state *__restrict__ state,
+                               const dev_hyp *__restrict__ h5, const float *__restrict__ sync5,
+                               const uint8_t *__restrict__ sym5, uwspr_demod_out *__restrict__ out,
+                               int nslots) {
+  const int slot = blockIdx.x;
+  if (slot >= nslots) return;
+  const cand_state st = state[slot];
+  uwspr_demod_out *o = out + slot;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    o->f1 = st.f1; o->drift1 = st.drift1; o->sync1 = st.sync1; o->shift1 = st.shift1;
+    o->worth_a_try = st.worth; o->_pad[0] = 0; o->_pad[1] = 0;
+  }
+  const bool on = st.frame >= 0 && st.worth;
+  if (tid < UWSPR_NJIG) {
+    const size_t q = (size_t)slot * UWSPR_NJIG + tid;
+    float rms = 0.0f;
+    if (on) {
+      float sq = 0.0f;
+      for (int i = 0; i < UWSPR_NSYM; i++) {
+        const float y = (float)((double)(float)sym5[q * UWSPR_NSYM + i] - 128.0);  // cc:471
+        sq += y * y;
+      }
+      rms = (float)sqrt((double)sq / 162.0);  // cc:474
+    }
+    o->jig_sync[tid] = on ? sync5[q] : 0.0f;
+    o->jig_rms[tid] = rms;
+    o->jig_shift[tid] = on ? h5[q].lag : 0;
+  }
+  for (int e = tid; e < UWSPR_NJIG * UWSPR_NSYM; e += blockDim.x)
+    (&o->symbols[0][0])[e] = on ? sym5[(size_t)slot * UWSPR_NJIG * UWSPR_NSYM + e] : (uint8_t)0;
+}
+
+void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t *npk,
+                       int cand_stride, int B, int per_frame) {
+  const int nslots = B * per_frame;
+  prof_scope ps(c, UWSPR_K_SCHED, nslots);
+  hipLaunchKernelGGL(k_sched_init, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, cands,
+                     npk, cand_stride, B, per_frame, (float)c->p.cf, c->d_state, c->d_hyps);
+}
+
+// hyps of consecutive stages ping-pong between the two halves of d_hyps
+void launch_sched_step(uwspr_ctx *c, int stage, int nslots) {
+  prof_scope ps(c, UWSPR_K_SCHED, nslots);
+  dev_hyp *half0 = c->d_hyps, *half1 = c->d_hyps + (size_t)nslots * UWSPR_NJIG;
+  dev_hyp *hin = (stage & 1) ? half0 : half1;
+  dev_hyp *hout = (stage & 1) ? half1 : half0;
+  dim3 g((nslots + 255) / 256), b(256);
+  switch (stage) {
+    case 1: hipLaunchKernelGGL(k_sched_step<1>, g, b, 0, c->stream, c->d_state, hin, c->d_sync, hout, nslots); break;
+    case 2: hipLaunchKernelGGL(k_sched_step<2>, g, b, 0, c->stream, c->d_state, hin, c->d_sync, hout, nslots); break;
+    case 3: hipLaunchKernelGGL(k_sched_step<3>, g, b, 0, c->stream, c->d_state, hin, c->d_sync, hout, nslots); break;
+    case 4: hipLaunchKernelGGL(k_sched_step<4>, g, b, 0, c->stream, c->d_state, hin, c->d_sync, hout, nslots); break;
+    default: hipLaunchKernelGGL(k_sched_step<5>, g, b, 0, c->stream, c->d_state, hin, c->d_sync, hout, nslots); break;
+  }
+}
+
+void launch_sched_finish(uwspr_ctx *c, int nslots) {
+  prof_scope ps(c, UWSPR_K_SCHED, nslots);
+  // stage-5 hyps live in the half selected by (5 & 1) -> half1
+  dev_hyp *h5 = c->d_hyps + (size_t)nslots * UWSPR_NJIG;
+  hipLaunchKernelGGL(k_sched_finish, dim3(nslots), dim3(256), 0, c->stream, c->d_state, h5,
+                     c->d_sync, c->d_sym, c->d_dout, nslots);
+}
+
+}  // namespace uwspr

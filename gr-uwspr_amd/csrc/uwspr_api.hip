@@ -1,0 +1,603 @@
+// uwspr_api.hip -- the C ABI of include/uwspr_hip.h: context set-up (the
+// constructors of FDR_impl / sync_and_demodulate_impl), constant tables, HBM
+// scratch management and the launch sequences.  There is no CPU fallback: with
+// no usable HIP device every entry point fails with UWSPR_ERR_NODEVICE.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "uwspr_internal.h"
+
+namespace uwspr {
+int coarse_configure(const fdr_consts &f);
+size_t coarse_lds_bytes(const fdr_consts &f);
+}  // namespace uwspr
+
+using namespace uwspr;
+
+// --------------------------------------------------------------- utilities
+static int fail(uwspr_ctx *c, int status, const char *fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof(c->err), fmt, ap);
+    va_end(ap);
+  }
+  return status;
+}
+
+#define HIPCHK(c, call)                                                                  \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess)                                                                \
+      return fail((c), UWSPR_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                   \
+  } while (0)
+
+template <typename T>
+static int ensure(uwspr_ctx *c, T **buf, size_t *cap, size_t need_elems) {
+  if (need_elems <= *cap && *buf) return UWSPR_OK;
+  if (*buf) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(*buf)); *buf = nullptr; *cap = 0; }
+  size_t n = std::max<size_t>(need_elems, 1);
+  hipError_t e = hipMalloc((void **)buf, n * sizeof(T));
+  if (e != hipSuccess) return fail(c, UWSPR_ERR_NOMEM, "hipMalloc(%zu bytes): %s", n * sizeof(T), hipGetErrorString(e));
+  *cap = n;
+  return UWSPR_OK;
+}
+
+prof_scope::prof_scope(uwspr_ctx *cx, int kind, int64_t units) : c(cx), idx(-1) {
+  if (!c->prof_on) return;
+  ev_pair p;
+  auto get = [&]() {
+    hipEvent_t e;
+    if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+    else (void)hipEventCreate(&e);
+    return e;
+  };
+  p.a = get(); p.b = get(); p.kind = kind; p.units = units;
+  (void)hipEventRecord(p.a, c->stream);
+  c->prof_events.push_back(p);
+  idx = (int)c->prof_events.size() - 1;
+}
+prof_scope::~prof_scope() {
+  if (idx >= 0) (void)hipEventRecord(c->prof_events[idx].b, c->stream);
+}
+
+// slmFrequencyDrift, lib/slm.cc:36-73 (host side, used to build the offset table)
+static float slm_frequency_drift(double V1, double V2, int p1, int p2, float cf, float t) {
+  const float cs = 1500.0f;
+  const double q1 = V1 * (double)t + (double)p1;
+  const double q2 = V2 * (double)t + (double)p2;
+  const float sign = (float)(((q1 * V1 + q2 * V2) > 0) * 2 - 1);
+  const double num = fabs(V1 * q1 + V2 * q2);
+  const double den = sqrt(q1 * q1 + q2 * q2);
+  if (den == 0) return 0.0f;
+  return (float)((double)(-sign) * num / den * (double)cf / (double)cs);
+}
+
+// ------------------------------------------------------------- ctx create
+extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **out) {
+  if (!p || !out) return UWSPR_ERR_ARG;
+  *out = nullptr;
+  uwspr_ctx *c = new (std::nothrow) uwspr_ctx();
+  if (!c) return UWSPR_ERR_NOMEM;
+  memset(c->err, 0, sizeof(c->err));
+  c->p = *p;
+  c->device = device;
+  c->own_stream = c->stream = nullptr;
+  c->d_window = c->d_twiddle = nullptr; c->d_off = nullptr;
+  c->cap_frames_bytes = 0; c->d_frames = nullptr; c->cap_B = 0;
+  c->d_ps = c->d_psavg = c->d_smraw = c->d_smspec = c->d_noise = nullptr;
+  c->d_cands = nullptr; c->d_npk = nullptr; c->last_B = 0;
+  c->grid_cap = 0; c->cap_grid_bytes = 0; c->d_syncgrid = nullptr;
+  c->cap_hyps = 0; c->d_hyps = nullptr; c->cap_abi_hyps = 0; c->d_abi_hyps = nullptr;
+  c->cap_p = 0; c->d_p = nullptr; c->cap_sync = 0; c->d_sync = nullptr;
+  c->cap_sym = 0; c->d_sym = nullptr; c->cap_state = 0; c->d_state = nullptr;
+  c->cap_dout = 0; c->d_dout = nullptr; c->prof_on = false;
+  *out = c;  // handed back even on failure so uwspr_last_error() can be read
+
+  fdr_consts &f = c->fc;
+  memset(&f, 0, sizeof(f));
+  // FDR_impl.cc:81-141
+  const int size = 2 * p->spb;
+  const int maxfreq = (int)((float)p->fs / 2.0);
+  if (p->halfbandwidth > maxfreq)
+    return fail(c, UWSPR_ERR_PARAM, "Half pass bandwidth (%d) must be lower than max freq range (%d)",
+                p->halfbandwidth, maxfreq);
+  if (p->spb != 256) return fail(c, UWSPR_ERR_UNSUPPORTED, "spb=%d: this build implements the 512-point transform (spb=256)", p->spb);
+  if (p->fs <= 0 || p->fl <= 0 || p->maxdrift < 0 || p->maxfreqs < 1 || p->halfbandwidth < 1 || p->cf <= 0)
+    return fail(c, UWSPR_ERR_ARG, "non-positive constructor argument");
+  f.fl = p->fl; f.size = size; f.m = size / 2; f.maxfreqs = p->maxfreqs; f.maxdrift = p->maxdrift;
+  f.df = (float)p->fs / (float)size;
+  f.hpbm = (int)ceil((float)(int)(float)p->halfbandwidth / f.df);
+  f.n = (int)(floor(((float)p->fl / (float)p->spb) * 2.0) - 3);
+  f.finpb = 2 * f.hpbm;
+  f.noiseidx = (int)floor(0.3 * (float)f.finpb);
+  f.min_snr = (float)pow(10.0, -7.0 / 10.0);
+  f.min_snr_floor = (float)(0.1 * (double)f.min_snr);
+  f.threshold = (float)p->threshold;
+  if (f.n < 2 * (UWSPR_NSYM - 1) + UWSPR_NK0 || (f.n - 1) * (p->spb / 2) + size > p->fl)
+    return fail(c, UWSPR_ERR_UNSUPPORTED, "fl=%d too short for 162 symbols + 26 half-symbol offsets", p->fl);
+  if (f.finpb > 512 || f.finpb < 3) return fail(c, UWSPR_ERR_RANGE, "pass band of %d bins", f.finpb);
+
+  // ---- offset table: ifd - ifr for every (ifr, hypothesis, symbol) --------
+  f.nlin = 2 * p->maxdrift + 1;
+  f.cell_hyps = f.nlin + UWSPR_NSLM;
+  f.ntot = UWSPR_NIFR * UWSPR_NK0 * f.cell_hyps;
+  f.ifr_lo = f.m - f.hpbm + 1 - 2;
+  const int ifr_hi = f.m + f.hpbm - 2 + 2;
+  f.n_ifr = ifr_hi - f.ifr_lo + 1;
+  // SLM drift in bins is independent of ifr; cache slmFrequencyDrift per (instance, t)
+  std::vector<float> slm((size_t)UWSPR_NSLM * 111);
+  for (int s = 0; s < UWSPR_NSLM; s++) {
+    const double V1 = (double)((s / 5) % 5) - 2.0, V2 = (double)(s / 25) - 2.0;  // slm.cc:103-109
+    const int p2 = 50 + 200 * (s % 5);
+    for (int t = 0; t < 111; t++)
+      slm[(size_t)s * 111 + t] = slm_frequency_drift(V1, V2, 0, p2, (float)p->cf, (float)t);
+  }
+  std::vector<int8_t> off((size_t)f.n_ifr * f.cell_hyps * 164, 0);
+  int omin = 1 << 30, omax = -(1 << 30);
+  for (int r = 0; r < f.n_ifr; r++) {
+    const int ifr = f.ifr_lo + r;
+    for (int h = 0; h < f.cell_hyps; h++) {
+      for (int k = 0; k < UWSPR_NSYM; k++) {
+        int ifd;
+        if (h < f.nlin) {
+          const int drift = h - p->maxdrift;
+          // FDR_impl.cc:353 (binary64 expression, truncated)
+          ifd = (int)((double)ifr + ((double)(float)k - 81.0) / 81.0 * (double)(float)drift /
+                                        (2.0 * (double)f.df));
+        } else {
+          // FDR_impl.cc:382-385: t = k*111/162 (integer division), binary32 add, truncated
+          const int t = k * 111 / 162;
+          ifd = (int)((float)ifr + slm[(size_t)(h - f.nlin) * 111 + t] / f.df);
+        }
+        const int o = ifd - ifr;
+        if (o < -128 || o > 127) return fail(c, UWSPR_ERR_RANGE, "search reach %d bins", o);
+        omin = std::min(omin, o); omax = std::max(omax, o);
+        off[((size_t)r * f.cell_hyps + h) * 164 + k] = (int8_t)o;
+      }
+    }
+  }
+  f.off_min = omin; f.off_max = omax; f.nc = UWSPR_NIFR + (omax - omin);
+  const int lo = std::min(f.m - f.hpbm - 3, f.ifr_lo + omin - 3);
+  const int hi = std::max(f.m + f.hpbm - 1 + 3, ifr_hi + omax + 3);
+  if (lo < 0 || hi > size - 1)
+    return fail(c, UWSPR_ERR_RANGE,
+                "halfbandwidth=%d: pass band + search reach needs columns %d..%d of 0..%d "
+                "(the reference reads out of bounds here)", p->halfbandwidth, lo, hi, size - 1);
+  f.band_lo = lo; f.band_w = hi - lo + 1;
+  f.cand_slots = std::min(p->maxfreqs, std::max(1, (f.finpb - 1) / 2));
+  if (coarse_lds_bytes(f) > 160 * 1024)
+    return fail(c, UWSPR_ERR_UNSUPPORTED, "coarse search needs %zu B of LDS (> 160 KiB): reduce maxdrift/cf",
+                coarse_lds_bytes(f));
+
+  // ---- device -------------------------------------------------------------
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(c, UWSPR_ERR_NODEVICE, "no HIP device visible; this library has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(c, UWSPR_ERR_ARG, "device %d of %d", device, ndev);
+  HIPCHK(c, hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(c, hipGetDeviceProperties(&prop, device));
+  snprintf(c->device_name, sizeof(c->device_name), "%s", prop.gcnArchName);
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(c, UWSPR_ERR_NODEVICE, "device %d is %s; kernels are built for gfx950 only", device,
+                prop.gcnArchName);
+  HIPCHK(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+
+  // window (FDR_impl.cc:101-105) and twiddles (exp(-2*pi*i*k/512), k<256; k=0,128 exact)
+  std::vector<float> w(size), tw(size);
+  for (int i = 0; i < size; i++) w[i] = (float)sin((M_PI / (size - 1)) * i);
+  for (int k = 0; k < size / 2; k++) {
+    const double ang = 2.0 * M_PI * (double)k / 512.0;
+    tw[2 * k] = (float)cos(ang);
+    tw[2 * k + 1] = (float)(-sin(ang));
+  }
+  tw[0] = 1.0f; tw[1] = 0.0f; tw[256] = 0.0f; tw[257] = -1.0f;
+  // pack offsets 4 symbols per word, [ifr][k4][h]
+  std::vector<uint32_t> offw((size_t)f.n_ifr * 41 * f.cell_hyps);
+  for (int r = 0; r < f.n_ifr; r++)
+    for (int k4 = 0; k4 < 41; k4++)
+      for (int h = 0; h < f.cell_hyps; h++) {
+        uint32_t v = 0;
+        for (int kk = 0; kk < 4; kk++)
+          v |= (uint32_t)(uint8_t)off[((size_t)r * f.cell_hyps + h) * 164 + 4 * k4 + kk] << (8 * kk);
+        offw[((size_t)r * 41 + k4) * f.cell_hyps + h] = v;
+      }
+  HIPCHK(c, hipMalloc((void **)&c->d_window, size * sizeof(float)));
+  HIPCHK(c, hipMalloc((void **)&c->d_twiddle, size * sizeof(float)));
+  HIPCHK(c, hipMalloc((void **)&c->d_off, offw.size() * sizeof(uint32_t)));
+  HIPCHK(c, hipMemcpy(c->d_window, w.data(), size * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_twiddle, tw.data(), size * sizeof(float), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_off, offw.data(), offw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (coarse_configure(f) != 0) return fail(c, UWSPR_ERR_HIP, "cannot reserve %zu B of LDS for the coarse search", coarse_lds_bytes(f));
+  return UWSPR_OK;
+}
+
+extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
+  if (!c) return;
+  if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
+  void *bufs[] = {c->d_window, c->d_twiddle, c->d_off, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
+                  c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_syncgrid, c->d_hyps,
+                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout};
+  for (void *b : bufs) if (b) (void)hipFree(b);
+  for (auto &e : c->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+extern "C" const char *uwspr_last_error(const uwspr_ctx *c) { return c ? c->err : "null context"; }
+
+extern "C" const char *uwspr_status_string(int s) {
+  switch (s) {
+    case UWSPR_OK: return "ok";
+    case UWSPR_ERR_PARAM: return "half pass bandwidth above fs/2";
+    case UWSPR_ERR_RANGE: return "pass band plus search reach outside the spectrum";
+    case UWSPR_ERR_UNSUPPORTED: return "unsupported geometry";
+    case UWSPR_ERR_HIP: return "HIP runtime error";
+    case UWSPR_ERR_NOMEM: return "out of memory";
+    case UWSPR_ERR_ARG: return "bad argument";
+    case UWSPR_ERR_NODEVICE: return "no gfx950 device (no CPU fallback)";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int uwspr_get_info(const uwspr_ctx *c, uwspr_info *o) {
+  if (!c || !o) return UWSPR_ERR_ARG;
+  const fdr_consts &f = c->fc;
+  memset(o, 0, sizeof(*o));
+  o->abi_version = UWSPR_ABI_VERSION;
+  o->size = f.size; o->m = f.m; o->hpbm = f.hpbm; o->n = f.n; o->finpb = f.finpb;
+  o->noiseidx = f.noiseidx; o->df = f.df; o->min_snr = f.min_snr;
+  o->band_lo = f.band_lo; o->band_w = f.band_w; o->cell_hyps = f.cell_hyps;
+  o->off_min = f.off_min; o->off_max = f.off_max; o->device = c->device;
+  snprintf(o->device_name, sizeof(o->device_name), "%s", c->device_name);
+  return UWSPR_OK;
+}
+
+static int ready(uwspr_ctx *c) {
+  if (!c) return UWSPR_ERR_ARG;
+  if (!c->own_stream) return fail(c, UWSPR_ERR_NODEVICE, "context has no device (creation failed: %s)", c->err);
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return fail(c, UWSPR_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_set_stream(uwspr_ctx *c, void *s) {
+  int rc = ready(c);
+  if (rc) return rc;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_synchronize(uwspr_ctx *c) {
+  int rc = ready(c);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWSPR_OK;
+}
+
+// frames -> device pointer (staged when they are host memory)
+static int frames_on_device(uwspr_ctx *c, const float *frames, int B, int where, const float **dev) {
+  if (!frames || B <= 0) return fail(c, UWSPR_ERR_ARG, "frames=%p B=%d", (const void *)frames, B);
+  if (where == UWSPR_DEVICE) { *dev = frames; return UWSPR_OK; }
+  if (where != UWSPR_HOST) return fail(c, UWSPR_ERR_ARG, "where=%d", where);
+  const size_t bytes = (size_t)B * c->fc.fl * 2 * sizeof(float);
+  size_t cap = c->cap_frames_bytes / sizeof(float);
+  int rc = ensure(c, &c->d_frames, &cap, bytes / sizeof(float));
+  c->cap_frames_bytes = cap * sizeof(float);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_frames, frames, bytes, hipMemcpyHostToDevice, c->stream));
+  *dev = c->d_frames;
+  return UWSPR_OK;
+}
+
+static int copy_out(uwspr_ctx *c, void *dst, const void *src, size_t bytes, int where) {
+  if (!dst || bytes == 0) return UWSPR_OK;
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, where == UWSPR_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
+  return UWSPR_OK;
+}
+
+// -------------------------------------------------------------------- FDR
+static int ensure_fdr(uwspr_ctx *c, int B) {
+  const fdr_consts &f = c->fc;
+  if (B <= c->cap_B) return UWSPR_OK;
+  size_t cap;
+  int rc;
+#define GROW(ptr, elems) cap = 0; if (ptr) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(ptr)); ptr = nullptr; } \
+  rc = ensure(c, &ptr, &cap, (size_t)(elems)); if (rc) return rc;
+  GROW(c->d_ps, (size_t)B * f.n * f.band_w);
+  GROW(c->d_psavg, (size_t)B * f.band_w);
+  GROW(c->d_smraw, (size_t)B * f.finpb);
+  GROW(c->d_smspec, (size_t)B * f.finpb);
+  GROW(c->d_noise, (size_t)B);
+  GROW(c->d_cands, (size_t)B * f.maxfreqs);
+  GROW(c->d_npk, (size_t)B);
+#undef GROW
+  c->cap_B = B;
+  return UWSPR_OK;
+}
+
+static int run_fdr(uwspr_ctx *c, const float *dframes, int B) {
+  int rc = ensure_fdr(c, B);
+  if (rc) return rc;
+  if (c->grid_cap > 0) {
+    size_t cap = c->cap_grid_bytes / sizeof(float);
+    rc = ensure(c, &c->d_syncgrid, &cap, (size_t)B * c->grid_cap * c->fc.ntot);
+    c->cap_grid_bytes = cap * sizeof(float);
+    if (rc) return rc;
+  }
+  launch_spectrogram(c, dframes, B);
+  launch_spectrum(c, B);
+  launch_coarse(c, B);
+  HIPCHK(c, hipGetLastError());
+  c->last_B = B;
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_fdr_batch(uwspr_ctx *c, const float *frames, int B, int where,
+                               uwspr_candidate *cands, int32_t *npk) {
+  int rc = ready(c);
+  if (rc) return rc;
+  const float *d;
+  if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
+  if ((rc = run_fdr(c, d, B))) return rc;
+  if ((rc = copy_out(c, cands, c->d_cands, (size_t)B * c->fc.maxfreqs * sizeof(uwspr_candidate), where))) return rc;
+  if ((rc = copy_out(c, npk, c->d_npk, (size_t)B * sizeof(int32_t), where))) return rc;
+  if (where == UWSPR_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_fdr_read_spectrum(uwspr_ctx *c, int B, float *ps_band, float *psavg, float *smraw,
+                                       float *smspec, float *noise) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (B <= 0 || B > c->last_B) return fail(c, UWSPR_ERR_ARG, "B=%d but the last FDR batch held %d frames", B, c->last_B);
+  const fdr_consts &f = c->fc;
+  if ((rc = copy_out(c, ps_band, c->d_ps, (size_t)B * f.n * f.band_w * 4, UWSPR_HOST))) return rc;
+  if ((rc = copy_out(c, psavg, c->d_psavg, (size_t)B * f.band_w * 4, UWSPR_HOST))) return rc;
+  if ((rc = copy_out(c, smraw, c->d_smraw, (size_t)B * f.finpb * 4, UWSPR_HOST))) return rc;
+  if ((rc = copy_out(c, smspec, c->d_smspec, (size_t)B * f.finpb * 4, UWSPR_HOST))) return rc;
+  if ((rc = copy_out(c, noise, c->d_noise, (size_t)B * 4, UWSPR_HOST))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_fdr_keep_syncgrid(uwspr_ctx *c, int ncand_cap) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (ncand_cap < 0) return fail(c, UWSPR_ERR_ARG, "ncand_cap=%d", ncand_cap);
+  c->grid_cap = std::min(ncand_cap, c->fc.cand_slots);
+  if (c->grid_cap == 0 && c->d_syncgrid) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(c->d_syncgrid));
+    c->d_syncgrid = nullptr; c->cap_grid_bytes = 0;
+  }
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_fdr_read_syncgrid(uwspr_ctx *c, int B, float *grid) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!c->d_syncgrid || c->grid_cap <= 0) return fail(c, UWSPR_ERR_ARG, "sync grid not kept: call uwspr_fdr_keep_syncgrid first");
+  if (B <= 0 || B > c->last_B) return fail(c, UWSPR_ERR_ARG, "B=%d but the last FDR batch held %d frames", B, c->last_B);
+  if ((rc = copy_out(c, grid, c->d_syncgrid, (size_t)B * c->grid_cap * c->fc.ntot * 4, UWSPR_HOST))) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWSPR_OK;
+}
+
+// ------------------------------------------------------------- fine sweep
+static int ensure_sweep(uwspr_ctx *c, size_t H, bool soft) {
+  int rc;
+  if ((rc = ensure(c, &c->d_p, &c->cap_p, H * UWSPR_NSYM))) return rc;
+  if ((rc = ensure(c, &c->d_sync, &c->cap_sync, H))) return rc;
+  if (soft && (rc = ensure(c, &c->d_sym, &c->cap_sym, H * UWSPR_NSYM))) return rc;
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_sync_sweep(uwspr_ctx *c, const float *frames, int B, const uwspr_hyp *hyps, int H,
+                                int where, float *sync, uint8_t *symbols) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!hyps || H <= 0) return fail(c, UWSPR_ERR_ARG, "hyps=%p H=%d", (const void *)hyps, H);
+  const float *d;
+  if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
+  if ((rc = ensure(c, &c->d_hyps, &c->cap_hyps, (size_t)H))) return rc;
+  const uwspr_hyp *dabi = hyps;
+  if (where == UWSPR_HOST) {
+    for (int h = 0; h < H; h++)
+      if (hyps[h].frame >= B) return fail(c, UWSPR_ERR_ARG, "hyps[%d].frame=%d >= B=%d", h, hyps[h].frame, B);
+    if ((rc = ensure(c, &c->d_abi_hyps, &c->cap_abi_hyps, (size_t)H))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_abi_hyps, hyps, (size_t)H * sizeof(uwspr_hyp), hipMemcpyHostToDevice, c->stream));
+    dabi = c->d_abi_hyps;
+  }
+  const bool soft = symbols != nullptr;
+  if ((rc = ensure_sweep(c, (size_t)H, soft))) return rc;
+  launch_prep_hyps(c, dabi, c->d_hyps, H);
+  launch_tonecorr(c, d, B, c->d_hyps, H, c->d_p);
+  launch_fold(c, c->d_hyps, c->d_p, H, c->d_sync, soft ? c->d_sym : nullptr);
+  HIPCHK(c, hipGetLastError());
+  if ((rc = copy_out(c, sync, c->d_sync, (size_t)H * 4, where))) return rc;
+  if (soft && (rc = copy_out(c, symbols, c->d_sym, (size_t)H * UWSPR_NSYM, where))) return rc;
+  if (where == UWSPR_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_sync_and_demodulate_batch(uwspr_ctx *c, const float *frames, int B, int where,
+                                               const uwspr_sync_call *calls, int ncalls,
+                                               uwspr_sync_result *results) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!calls || !results || ncalls <= 0) return fail(c, UWSPR_ERR_ARG, "calls/results/ncalls");
+  // expand each call into its (ifreq, lag) loop, cc:160-165
+  std::vector<uwspr_hyp> hyps;
+  std::vector<size_t> first(ncalls + 1, 0);
+  bool soft = false;
+  for (int q = 0; q < ncalls; q++) {
+    const uwspr_sync_call &k = calls[q];
+    if (k.mode < 0 || k.mode > 2) return fail(c, UWSPR_ERR_ARG, "calls[%d].mode=%d", q, k.mode);
+    if (k.symfac != 50) return fail(c, UWSPR_ERR_UNSUPPORTED, "calls[%d].symfac=%d (the path uses 50)", q, k.symfac);
+    if (k.frame < 0 || k.frame >= B) return fail(c, UWSPR_ERR_ARG, "calls[%d].frame=%d", q, k.frame);
+    if (q > 0 && k.frame < calls[q - 1].frame) return fail(c, UWSPR_ERR_ARG, "calls must be grouped by non-decreasing frame");
+    int ifmin = k.ifmin, ifmax = k.ifmax, lagmin = k.lagmin, lagmax = k.lagmax;
+    float fstep = k.fstep;
+    if (k.mode == 0) { ifmin = 0; ifmax = 0; fstep = 0.0f; }
+    if (k.mode == 1) { lagmin = k.shift1; lagmax = k.shift1; }
+    if (k.mode == 2) { lagmin = k.shift1; lagmax = k.shift1; ifmin = 0; ifmax = 0; soft = true; }
+    if (k.lagstep <= 0) return fail(c, UWSPR_ERR_ARG, "calls[%d].lagstep=%d", q, k.lagstep);
+    first[q] = hyps.size();
+    for (int ifreq = ifmin; ifreq <= ifmax; ifreq++) {
+      const float f0 = k.f1 + (float)ifreq * fstep;  // cc:164
+      for (int lag = lagmin; lag <= lagmax; lag += k.lagstep) {
+        uwspr_hyp h;
+        memset(&h, 0, sizeof(h));
+        h.frame = k.frame; h.m_type = k.candidate.m_type; h.f0 = f0; h.lag = lag;
+        h.drift = k.drift1;
+        if (k.candidate.m_type == UWSPR_NONLINEAR) {
+          h.V1 = k.candidate.m_nonlinear.V1; h.V2 = k.candidate.m_nonlinear.V2;
+          h.p1 = k.candidate.m_nonlinear.p1; h.p2 = k.candidate.m_nonlinear.p2;
+        }
+        hyps.push_back(h);
+        if (hyps.size() > (size_t)1 << 26) return fail(c, UWSPR_ERR_ARG, "more than 2^26 hypotheses in one batch");
+      }
+    }
+  }
+  first[ncalls] = hyps.size();
+  const int H = (int)hyps.size();
+  std::vector<float> sync(std::max(H, 1));
+  std::vector<uint8_t> sym(soft ? (size_t)std::max(H, 1) * UWSPR_NSYM : 0);
+  if (H > 0) {
+    // frames may be device memory while the call records are host memory
+    const float *d;
+    if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
+    if ((rc = ensure(c, &c->d_hyps, &c->cap_hyps, (size_t)H))) return rc;
+    if ((rc = ensure(c, &c->d_abi_hyps, &c->cap_abi_hyps, (size_t)H))) return rc;
+    if ((rc = ensure_sweep(c, (size_t)H, soft))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_abi_hyps, hyps.data(), (size_t)H * sizeof(uwspr_hyp), hipMemcpyHostToDevice, c->stream));
+    launch_prep_hyps(c, c->d_abi_hyps, c->d_hyps, H);
+    launch_tonecorr(c, d, B, c->d_hyps, H, c->d_p);
+    launch_fold(c, c->d_hyps, c->d_p, H, c->d_sync, soft ? c->d_sym : nullptr);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(sync.data(), c->d_sync, (size_t)H * 4, hipMemcpyDeviceToHost, c->stream));
+    if (soft) HIPCHK(c, hipMemcpyAsync(sym.data(), c->d_sym, (size_t)H * UWSPR_NSYM, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  for (int q = 0; q < ncalls; q++) {
+    const uwspr_sync_call &k = calls[q];
+    uwspr_sync_result &r = results[q];
+    memset(&r, 0, sizeof(r));
+    float syncmax = -1e30f, fbest = 0.0f;   // cc:156-159
+    int best_shift = 0;
+    for (size_t h = first[q]; h < first[q + 1]; h++)
+      if (sync[h] > syncmax) { syncmax = sync[h]; best_shift = hyps[h].lag; fbest = hyps[h].f0; }  // cc:227-231
+    r.sync = syncmax;
+    if (k.mode <= 1) { r.shift1 = best_shift; r.f1 = fbest; }            // cc:234-238
+    else {
+      r.shift1 = k.shift1; r.f1 = k.f1;                                  // mode 2 leaves them alone
+      if (first[q + 1] > first[q]) memcpy(r.symbols, &sym[(first[q + 1] - 1) * UWSPR_NSYM], UWSPR_NSYM);
+    }
+  }
+  return UWSPR_OK;
+}
+
+// ------------------------------------------------------ refinement schedule
+static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_candidate *dcands,
+                        const int32_t *dnpk, int cand_stride, int per_frame) {
+  static const int hpc[6] = {5, 5, 2, 5, 5, UWSPR_NJIG};
+  const size_t nslots = (size_t)B * per_frame;
+  int rc;
+  if ((rc = ensure(c, &c->d_state, &c->cap_state, nslots))) return rc;
+  if ((rc = ensure(c, &c->d_hyps, &c->cap_hyps, 2 * nslots * UWSPR_NJIG))) return rc;
+  if ((rc = ensure_sweep(c, nslots * UWSPR_NJIG, true))) return rc;
+  if ((rc = ensure(c, &c->d_dout, &c->cap_dout, nslots))) return rc;
+  dev_hyp *half[2] = {c->d_hyps, c->d_hyps + nslots * UWSPR_NJIG};
+  launch_sched_init(c, dcands, dnpk, cand_stride, B, per_frame);
+  for (int s = 0; s < 6; s++) {
+    const int H = (int)(nslots * hpc[s]);
+    const dev_hyp *h = half[s & 1];
+    launch_tonecorr(c, dframes, B, h, H, c->d_p);
+    launch_fold(c, h, c->d_p, H, c->d_sync, s == 5 ? c->d_sym : nullptr);
+    if (s < 5) launch_sched_step(c, s + 1, (int)nslots);
+    else launch_sched_finish(c, (int)nslots);
+  }
+  HIPCHK(c, hipGetLastError());
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_demod_batch(uwspr_ctx *c, const float *frames, int B, int where,
+                                 const uwspr_candidate *cands, const int32_t *npk, int cand_stride,
+                                 int max_per_frame, uwspr_demod_out *out) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!cands || !npk || cand_stride <= 0 || max_per_frame <= 0 || !out)
+    return fail(c, UWSPR_ERR_ARG, "cands/npk/cand_stride/max_per_frame/out");
+  const float *d;
+  if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
+  const uwspr_candidate *dc = cands;
+  const int32_t *dn = npk;
+  uwspr_candidate *tmpc = nullptr; int32_t *tmpn = nullptr;
+  if (where == UWSPR_HOST) {
+    HIPCHK(c, hipMalloc((void **)&tmpc, (size_t)B * cand_stride * sizeof(uwspr_candidate)));
+    HIPCHK(c, hipMalloc((void **)&tmpn, (size_t)B * sizeof(int32_t)));
+    HIPCHK(c, hipMemcpyAsync(tmpc, cands, (size_t)B * cand_stride * sizeof(uwspr_candidate), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(tmpn, npk, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    dc = tmpc; dn = tmpn;
+  }
+  rc = run_schedule(c, d, B, dc, dn, cand_stride, max_per_frame);
+  if (!rc) rc = copy_out(c, out, c->d_dout, (size_t)B * max_per_frame * sizeof(uwspr_demod_out), where);
+  if (where == UWSPR_HOST) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(tmpc); (void)hipFree(tmpn);
+  }
+  return rc;
+}
+
+extern "C" int uwspr_pipeline_batch(uwspr_ctx *c, const float *frames, int B, int where,
+                                    int max_per_frame, uwspr_candidate *cands, int32_t *npk,
+                                    uwspr_demod_out *out) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (max_per_frame <= 0) return fail(c, UWSPR_ERR_ARG, "max_per_frame=%d", max_per_frame);
+  const float *d;
+  if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
+  if ((rc = run_fdr(c, d, B))) return rc;
+  if ((rc = run_schedule(c, d, B, c->d_cands, c->d_npk, c->fc.maxfreqs, max_per_frame))) return rc;
+  if ((rc = copy_out(c, cands, c->d_cands, (size_t)B * c->fc.maxfreqs * sizeof(uwspr_candidate), where))) return rc;
+  if ((rc = copy_out(c, npk, c->d_npk, (size_t)B * sizeof(int32_t), where))) return rc;
+  if ((rc = copy_out(c, out, c->d_dout, (size_t)B * max_per_frame * sizeof(uwspr_demod_out), where))) return rc;
+  if (where == UWSPR_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWSPR_OK;
+}
+
+// -------------------------------------------------------------- profiling
+extern "C" int uwspr_prof_enable(uwspr_ctx *c, int on) {
+  int rc = ready(c);
+  if (rc) return rc;
+  c->prof_on = on != 0;
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_prof_read(uwspr_ctx *c, uwspr_prof *o) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!o) return UWSPR_ERR_ARG;
+  memset(o, 0, sizeof(*o));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto &e : c->prof_events) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      o->ms[e.kind] += ms; o->launches[e.kind] += 1; o->units[e.kind] += e.units;
+    }
+    c->ev_pool.push_back(e.a); c->ev_pool.push_back(e.b);
+  }
+  c->prof_events.clear();
+  return UWSPR_OK;
+}

@@ -1,0 +1,120 @@
+// uwspr_internal.h -- shared declarations of the HIP implementation
+// (context, device-side records, kernel launchers).  Not part of the ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+#include "../../include/uwspr_hip.h"
+
+namespace uwspr {
+
+// 162 WSPR sync bits (lib/pr3.h:5-13), LSB-first packed; a protocol constant.
+#define UWSPR_PR3_WORDS                                                        \
+  { 0x07a47103u, 0x58b340a4u, 0x56349558u, 0xe2cdc904u, 0x63580ca0u, 0x00000000u }
+__host__ __device__ constexpr uint32_t pr3_word(int w) {
+  constexpr uint32_t t[6] = UWSPR_PR3_WORDS;
+  return t[w];
+}
+__host__ __device__ constexpr int pr3_bit(int k) { return (pr3_word(k >> 5) >> (k & 31)) & 1; }
+
+// fine-grid hypothesis as the kernels consume it (24 B)
+struct dev_hyp {
+  int32_t frame;   // <0: skip
+  int32_t lag;
+  float f0;
+  float drift;     // linear: *drift1
+  float slmc;      // nonlinear: slmFrequencyDrift(m_nl, cf, t=0)
+  int32_t m_type;
+};
+
+// per-candidate refinement state kept in HBM between schedule stages
+struct cand_state {
+  int32_t frame;       // <0: empty slot
+  int32_t m_type;
+  float slmc;
+  float f1, drift1, sync1;
+  int32_t shift1;
+  int32_t worth;
+  float driftp, driftm;
+};
+
+struct fdr_consts {
+  int fl, n, size, m, hpbm, finpb, noiseidx, maxfreqs, maxdrift;
+  int band_lo, band_w;
+  int cell_hyps, nlin, ntot;      // hyps per (ifr,k0) cell; linear ones; 130*cell_hyps
+  int off_min, off_max, nc;       // ifd-ifr range; tile centres per row = 5 + off_max-off_min
+  int ifr_lo, n_ifr;              // rows of the offset table
+  int cand_slots;                 // max candidates a frame can yield
+  float df, min_snr, min_snr_floor, threshold;
+};
+
+struct ev_pair { hipEvent_t a, b; int kind; int64_t units; };
+
+}  // namespace uwspr
+
+struct uwspr_ctx {
+  uwspr_params p;
+  uwspr::fdr_consts fc;
+  int device;
+  char device_name[64];
+  hipStream_t own_stream, stream;
+  char err[512];
+
+  // constant tables in HBM
+  float *d_window;     // [512]
+  float *d_twiddle;    // [256][2]
+  uint32_t *d_off;     // [n_ifr][41][cell_hyps], 4 x int8 (ifd-ifr) per word
+
+  // batch scratch (grown on demand, never shrunk)
+  size_t cap_frames_bytes; float *d_frames;       // staging when frames are host memory
+  int cap_B;
+  float *d_ps;          // [B][n][band_w]
+  float *d_psavg;       // [B][band_w]
+  float *d_smraw;       // [B][finpb]
+  float *d_smspec;      // [B][finpb]
+  float *d_noise;       // [B]
+  uwspr_candidate *d_cands;  // [B][maxfreqs]
+  int32_t *d_npk;       // [B]
+  int last_B;
+  int grid_cap; size_t cap_grid_bytes; float *d_syncgrid;  // [B][grid_cap][ntot]
+
+  size_t cap_hyps; uwspr::dev_hyp *d_hyps;
+  size_t cap_abi_hyps; uwspr_hyp *d_abi_hyps;
+  size_t cap_p; float4 *d_p;                      // [H][162] tone magnitudes
+  size_t cap_sync; float *d_sync;                 // [H]
+  size_t cap_sym; uint8_t *d_sym;                 // [H][162]
+  size_t cap_state; uwspr::cand_state *d_state;
+  size_t cap_dout; uwspr_demod_out *d_dout;
+
+  bool prof_on;
+  std::vector<uwspr::ev_pair> prof_events;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+namespace uwspr {
+
+// ---- launchers (each enqueues on ctx->stream) ------------------------------
+void launch_spectrogram(uwspr_ctx *c, const float *frames, int B);
+void launch_spectrum(uwspr_ctx *c, int B);
+void launch_coarse(uwspr_ctx *c, int B);
+void launch_prep_hyps(uwspr_ctx *c, const uwspr_hyp *abi, dev_hyp *out, int H);
+void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int H,
+                     float4 *p);
+void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, float *sync,
+                 uint8_t *symbols);
+// schedule stages; see k5_schedule.hip
+void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t *npk,
+                       int cand_stride, int B, int per_frame);
+void launch_sched_step(uwspr_ctx *c, int stage, int ncand);
+void launch_sched_finish(uwspr_ctx *c, int ncand);
+
+// profiling brackets
+struct prof_scope {
+  uwspr_ctx *c; int idx;
+  prof_scope(uwspr_ctx *c, int kind, int64_t units);
+  ~prof_scope();
+};
+
+}  // namespace uwspr

@@ -1,0 +1,173 @@
+"""Build + ctypes binding of libuwspr_hip.so (include/uwspr_hip.h).
+
+This module is plumbing only: it compiles the HIP sources for gfx950 in-tree
+and maps the C ABI one-to-one.  There is no Python or CPU implementation of the
+path behind it: if the library cannot be built or loaded, or no gfx950 device
+is present, calls raise UwsprError.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIBDIR = os.path.join(_HERE, "lib")
+LIBPATH = os.path.join(LIBDIR, "libuwspr_hip.so")
+HOSTLIB = os.path.join(LIBDIR, "libuwspr_blocks.so")
+
+SOURCES = ["uwspr_api.hip", "k1_spectrogram.hip", "k2_spectrum.hip", "k3_coarse.hip",
+           "k4_tonecorr.hip", "k5_fold_schedule.hip", "host_tail.cpp"]
+HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+            "-fno-slp-vectorize", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+NSYM, NSLM, NK0, NIFR, NJIG = 162, 125, 26, 5, 17
+HOST, DEVICE = 0, 1
+LINEAR, NONLINEAR = 0, 1
+
+
+class UwsprError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("uwspr status %d: %s" % (status, msg))
+        self.status = status
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise UwsprError(-4, "hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 every kernel + the C ABI into lib/libuwspr_hip.so,
+    then the host block mirror (gr-uwspr_amd/host) into lib/libuwspr_blocks.so."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    deps.append(os.path.join(_HERE, "..", "include", "uwspr_hip.h"))
+    if force or _stale(LIBPATH, deps):
+        cmd = [_hipcc()] + HIPFLAGS + ["-shared"] + srcs + ["-o", LIBPATH]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True)
+    hostdir = os.path.join(_HERE, "host")
+    hsrcs = [os.path.join(hostdir, f) for f in sorted(os.listdir(hostdir)) if f.endswith(".cc")] \
+        if os.path.isdir(hostdir) else []
+    if hsrcs:
+        hdeps = hsrcs + [os.path.join(hostdir, f) for f in os.listdir(hostdir) if f.endswith(".h")]
+        if force or _stale(HOSTLIB, hdeps + [LIBPATH]):
+            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + hostdir,
+                   "-I" + os.path.join(_HERE, "..", "include")] + hsrcs + \
+                  ["-o", HOSTLIB, "-L" + LIBDIR, "-luwspr_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+    return LIBPATH
+
+
+# ---- ABI structures --------------------------------------------------------
+class Params(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in
+                ("fs", "fl", "spb", "maxdrift", "maxfreqs", "halfbandwidth", "cf", "threshold")]
+
+
+CAND_DTYPE = np.dtype([("freq", "<f4"), ("snr", "<f4"), ("drift", "<f4"), ("sync", "<f4"),
+                       ("shift", "<i4"), ("m_type", "<i4"), ("V1", "<f8"), ("V2", "<f8"),
+                       ("p1", "<i4"), ("p2", "<i4")])
+HYP_DTYPE = np.dtype([("frame", "<i4"), ("m_type", "<i4"), ("f0", "<f4"), ("lag", "<i4"),
+                      ("drift", "<f4"), ("p1", "<i4"), ("p2", "<i4"), ("_pad", "<i4"),
+                      ("V1", "<f8"), ("V2", "<f8")])
+DEMOD_DTYPE = np.dtype([("f1", "<f4"), ("drift1", "<f4"), ("sync1", "<f4"), ("shift1", "<i4"),
+                        ("worth_a_try", "<i4"), ("jig_sync", "<f4", (NJIG,)),
+                        ("jig_rms", "<f4", (NJIG,)), ("jig_shift", "<i4", (NJIG,)),
+                        ("symbols", "u1", (NJIG, NSYM)), ("_pad", "u1", (2,))])
+CALL_DTYPE = np.dtype([("frame", "<i4"), ("_p0", "<i4"), ("candidate", CAND_DTYPE),
+                       ("f1", "<f4"), ("ifmin", "<i4"), ("ifmax", "<i4"), ("fstep", "<f4"),
+                       ("shift1", "<i4"), ("lagmin", "<i4"), ("lagmax", "<i4"),
+                       ("lagstep", "<i4"), ("drift1", "<f4"), ("symfac", "<i4"),
+                       ("mode", "<i4"), ("_p1", "<i4")])
+RESULT_DTYPE = np.dtype([("sync", "<f4"), ("shift1", "<i4"), ("f1", "<f4"),
+                         ("symbols", "u1", (NSYM,)), ("_pad", "u1", (2,))])
+assert CAND_DTYPE.itemsize == 48 and HYP_DTYPE.itemsize == 48
+assert DEMOD_DTYPE.itemsize == 2980 and CALL_DTYPE.itemsize == 104 and RESULT_DTYPE.itemsize == 176
+
+
+class Info(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("size", C.c_int32), ("m", C.c_int32),
+                ("hpbm", C.c_int32), ("n", C.c_int32), ("finpb", C.c_int32),
+                ("noiseidx", C.c_int32), ("df", C.c_float), ("min_snr", C.c_float),
+                ("band_lo", C.c_int32), ("band_w", C.c_int32), ("cell_hyps", C.c_int32),
+                ("off_min", C.c_int32), ("off_max", C.c_int32), ("device", C.c_int32),
+                ("device_name", C.c_char * 64)]
+
+
+K_NAMES = ("spectrogram", "spectrum", "coarse", "tonecorr", "fold", "sched")
+
+
+class Prof(C.Structure):
+    _fields_ = [("ms", C.c_double * 6), ("launches", C.c_int64 * 6), ("units", C.c_int64 * 6)]
+
+
+# every symbol include/uwspr_hip.h declares
+ABI_SYMBOLS = [
+    "uwspr_ctx_create", "uwspr_ctx_destroy", "uwspr_last_error", "uwspr_status_string",
+    "uwspr_get_info", "uwspr_set_stream", "uwspr_synchronize", "uwspr_fdr_batch",
+    "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
+    "uwspr_sync_sweep", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
+    "uwspr_pipeline_batch", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_deinterleave",
+    "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_unpack_message",
+    "uwspr_c2_read",
+]
+
+_lib = None
+
+
+def lib():
+    """Load (building first if needed) the shared library.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIBPATH):
+        build()
+    L = C.CDLL(LIBPATH)
+    vp, ip = C.c_void_p, C.c_int
+    L.uwspr_ctx_create.argtypes = [C.POINTER(Params), ip, C.POINTER(vp)]
+    L.uwspr_ctx_destroy.argtypes = [vp]
+    L.uwspr_ctx_destroy.restype = None
+    L.uwspr_last_error.argtypes = [vp]
+    L.uwspr_last_error.restype = C.c_char_p
+    L.uwspr_status_string.argtypes = [ip]
+    L.uwspr_status_string.restype = C.c_char_p
+    L.uwspr_get_info.argtypes = [vp, C.POINTER(Info)]
+    L.uwspr_set_stream.argtypes = [vp, vp]
+    L.uwspr_synchronize.argtypes = [vp]
+    L.uwspr_fdr_batch.argtypes = [vp, vp, ip, ip, vp, vp]
+    L.uwspr_fdr_read_spectrum.argtypes = [vp, ip, vp, vp, vp, vp, vp]
+    L.uwspr_fdr_keep_syncgrid.argtypes = [vp, ip]
+    L.uwspr_fdr_read_syncgrid.argtypes = [vp, ip, vp]
+    L.uwspr_sync_sweep.argtypes = [vp, vp, ip, vp, ip, ip, vp, vp]
+    L.uwspr_sync_and_demodulate_batch.argtypes = [vp, vp, ip, ip, vp, ip, vp]
+    L.uwspr_demod_batch.argtypes = [vp, vp, ip, ip, vp, vp, ip, ip, vp]
+    L.uwspr_pipeline_batch.argtypes = [vp, vp, ip, ip, ip, vp, vp, vp]
+    L.uwspr_prof_enable.argtypes = [vp, ip]
+    L.uwspr_prof_read.argtypes = [vp, C.POINTER(Prof)]
+    L.uwspr_deinterleave.argtypes = [vp]
+    L.uwspr_deinterleave.restype = None
+    L.uwspr_fano_decode.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_uint32), ip, C.c_uint32]
+    L.uwspr_fano_encode.argtypes = [vp, vp, C.c_uint32]
+    L.uwspr_decode_candidate.argtypes = [vp, vp, C.POINTER(C.c_int32)]
+    L.uwspr_unpack_message.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.uwspr_c2_read.argtypes = [C.c_char_p, vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    _lib = L
+    return L

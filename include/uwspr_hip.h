@@ -1,0 +1,249 @@
+/*
+ * uwspr_hip.h -- C ABI of the MI355X (gfx950) implementation of gr-uwspr's
+ * coarse (FDR) + fine (sync_and_demodulate) search path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * A GNU Radio block shim (gr-uwspr_amd/host/) or any FFI (ctypes, cgo, JNI)
+ * binds exactly these symbols.  Each entry point cites the reference interface
+ * it replaces (paths relative to the upstream gr-uwspr tree).
+ *
+ * Conventions
+ *   - every function returns 0 (UWSPR_OK) or a negative uwspr_status; nothing
+ *     here calls exit() or throws (the reference does: lib/FDR_impl.cc:85-90).
+ *   - `where` says whether the bulk pointers of that call are host
+ *     (UWSPR_HOST) or device (UWSPR_DEVICE) memory; a call never mixes them.
+ *   - frames are interleaved (I,Q) binary32 pairs, `fl` pairs per frame,
+ *     frame b at frames + 2*fl*b: the payload of the PDU that
+ *     sliding_window_stream_to_pdu emits (lib/sliding_window_stream_to_pdu_impl.cc:113-135)
+ *     narrowed from complex<double> to the gr_complex it was built from (cc:109).
+ *   - a context is thread-compatible: one context per host thread; no globals.
+ */
+#ifndef UWSPR_HIP_H
+#define UWSPR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UWSPR_ABI_VERSION 1
+
+typedef enum {
+  UWSPR_OK = 0,
+  UWSPR_ERR_PARAM = -1,       /* halfbandwidth > fs/2 (reference exit(-1)s: FDR_impl.cc:85-90) */
+  UWSPR_ERR_RANGE = -2,       /* pass band + search reach leaves [0,size) (reference reads OOB) */
+  UWSPR_ERR_UNSUPPORTED = -3, /* geometry this build does not implement (spb != 256, ...) */
+  UWSPR_ERR_HIP = -4,         /* HIP runtime error, see uwspr_last_error() */
+  UWSPR_ERR_NOMEM = -5,
+  UWSPR_ERR_ARG = -6,         /* bad pointer / size / ordering in a call */
+  UWSPR_ERR_NODEVICE = -7     /* no usable gfx950 device: there is NO CPU fallback */
+} uwspr_status;
+
+enum { UWSPR_HOST = 0, UWSPR_DEVICE = 1 };
+enum { UWSPR_LINEAR = 0, UWSPR_NONLINEAR = 1 };   /* enum Modes, lib/candidate_t.h:36 */
+
+#define UWSPR_NSYM 162      /* symbols per frame */
+#define UWSPR_NSLM 125      /* straight-line-model instances, lib/slm.cc:79-87 */
+#define UWSPR_NK0 26        /* half-symbol start offsets, FDR_impl.cc:346 */
+#define UWSPR_NIFR 5        /* tuned bins if0-2..if0+2, FDR_impl.cc:344 */
+#define UWSPR_NJIG 17       /* jiggered shifts, sync_and_demodulate_impl.cc:460 */
+
+/* Constructor arguments of the two blocks:
+ * gr::uwspr::FDR::make(fs,fl,spb,maxdrift,maxfreqs,halfbandwidth,cf,threshold)
+ *   include/uwspr/FDR.h:49-50
+ * gr::uwspr::sync_and_demodulate::make(fs,fl,spb,maxdrift,maxfreqs,cf)
+ *   include/uwspr/sync_and_demodulate.h:49  (a subset of the above) */
+typedef struct uwspr_params {
+  int32_t fs;             /* 375 */
+  int32_t fl;             /* 45000 */
+  int32_t spb;            /* 256 */
+  int32_t maxdrift;       /* 0 */
+  int32_t maxfreqs;       /* 200 */
+  int32_t halfbandwidth;  /* 10 in the flowgraphs (the GRC default 187 is rejected: UWSPR_ERR_RANGE) */
+  int32_t cf;             /* 1500 */
+  int32_t threshold;      /* 10 */
+} uwspr_params;
+
+/* candidate_t, lib/candidate_t.h:27-50: same 48-byte layout, so a slab of
+ * these can be handed to code compiled against the reference header. */
+typedef struct uwspr_candidate {
+  float freq;
+  float snr;
+  float drift;     /* unused by the reference as well */
+  float sync;
+  int32_t shift;
+  int32_t m_type;  /* UWSPR_LINEAR / UWSPR_NONLINEAR */
+  union {
+    struct { float drift; } m_linear;
+    struct { double V1, V2; int32_t p1, p2; } m_nonlinear;
+  };
+} uwspr_candidate;
+
+/* One point of the fine (freq, time-lag, drift) grid: one pass of the
+ * ifreq/lag loop body of sync_and_demodulate_impl.cc:163-232. */
+typedef struct uwspr_hyp {
+  int32_t frame;   /* index into the frames of the call; <0 = skip */
+  int32_t m_type;
+  float f0;        /* Hz, the f0 of cc:164 */
+  int32_t lag;     /* samples, the lag of cc:165 */
+  float drift;     /* linear: *drift1 of cc:173 */
+  int32_t p1, p2;  /* nonlinear: candidate.m_nonlinear */
+  int32_t _pad;
+  double V1, V2;
+} uwspr_hyp;
+
+/* Result of the per-candidate refinement schedule
+ * (sync_and_demodulate_impl.cc:403-482) up to, not including, Fano: every
+ * one of the 17 jiggered mode-2 soft-symbol vectors is produced, in the order
+ * the reference tries them, with the sync and rms it gates Fano on. */
+typedef struct uwspr_demod_out {
+  float f1;
+  float drift1;
+  float sync1;
+  int32_t shift1;
+  int32_t worth_a_try;
+  float jig_sync[UWSPR_NJIG];
+  float jig_rms[UWSPR_NJIG];
+  int32_t jig_shift[UWSPR_NJIG];
+  uint8_t symbols[UWSPR_NJIG][UWSPR_NSYM];
+  uint8_t _pad[2];
+} uwspr_demod_out;
+
+/* Derived constants (FDR_impl.cc:81-141) and buffer geometry. */
+typedef struct uwspr_info {
+  int32_t abi_version;
+  int32_t size, m, hpbm, n, finpb, noiseidx;
+  float df, min_snr;
+  int32_t band_lo, band_w;     /* spectrogram columns kept: [band_lo, band_lo+band_w) */
+  int32_t cell_hyps;           /* (2*maxdrift+1) + 125 */
+  int32_t off_min, off_max;    /* range of ifd-ifr over the whole search */
+  int32_t device;
+  char device_name[64];
+} uwspr_info;
+
+typedef struct uwspr_ctx uwspr_ctx;
+
+/* ---- lifetime ---------------------------------------------------------- */
+/* Replaces FDR_impl::FDR_impl / sync_and_demodulate_impl ctor set-up
+ * (FDR_impl.cc:48-151, sync_and_demodulate_impl.cc:62-111). */
+int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **out);
+void uwspr_ctx_destroy(uwspr_ctx *ctx);
+const char *uwspr_last_error(const uwspr_ctx *ctx);
+const char *uwspr_status_string(int status);
+int uwspr_get_info(const uwspr_ctx *ctx, uwspr_info *info);
+/* Run on a caller-owned hipStream_t (NULL = the context's own stream).  All
+ * calls are asynchronous on that stream when where==UWSPR_DEVICE and complete
+ * before returning when where==UWSPR_HOST. */
+int uwspr_set_stream(uwspr_ctx *ctx, void *hip_stream);
+int uwspr_synchronize(uwspr_ctx *ctx);
+
+/* ---- coarse search: FDR_impl::transform, FDR_impl.cc:214-456 ------------ */
+/* cands: [B][maxfreqs] records; npk: [B].  Same candidate order, fields and
+ * selection rule (running-best, FDR_impl.cc:360,392) as the reference. */
+int uwspr_fdr_batch(uwspr_ctx *ctx, const float *frames, int B, int where,
+                    uwspr_candidate *cands, int32_t *npk);
+
+/* Inspection of the intermediates of the LAST uwspr_fdr_batch call (host
+ * pointers; any may be NULL):
+ *   ps_band [B][n][band_w]   FDR_impl.cc:246-253 (columns band_lo..)
+ *   psavg   [B][band_w]      cc:257-263
+ *   smraw   [B][finpb]       cc:268-275
+ *   smspec  [B][finpb]       cc:287-291
+ *   noise   [B]              cc:285 */
+int uwspr_fdr_read_spectrum(uwspr_ctx *ctx, int B, float *ps_band, float *psavg,
+                            float *smraw, float *smspec, float *noise);
+/* When enabled, the next uwspr_fdr_batch also keeps every hypothesis metric:
+ * grid [B][ncand_cap][5][26][cell_hyps] (cc:357,390), read back with
+ * uwspr_fdr_read_syncgrid.  Off by default (it is 65 KB per candidate). */
+int uwspr_fdr_keep_syncgrid(uwspr_ctx *ctx, int ncand_cap);
+int uwspr_fdr_read_syncgrid(uwspr_ctx *ctx, int B, float *grid);
+
+/* ---- fine sweep: core of sync_and_demodulate, cc:126-256 ---------------- */
+/* One metric per (freq, lag, drift) hypothesis.  hyps must be grouped by
+ * non-decreasing frame index.  sync: [H]; symbols: [H][162] soft symbols
+ * (cc:240-254) or NULL to skip them (modes 0/1). */
+int uwspr_sync_sweep(uwspr_ctx *ctx, const float *frames, int B,
+                     const uwspr_hyp *hyps, int H, int where, float *sync,
+                     uint8_t *symbols);
+
+/* Argument-for-argument batch form of sync_and_demodulate() (cc:126-131):
+ * one call = one invocation of the reference function; results are what it
+ * writes back through sync/shift1/f1 (and symbols in mode 2).  Host pointers
+ * for the call records; frames per `where`. */
+typedef struct uwspr_sync_call {
+  int32_t frame;
+  uwspr_candidate candidate;
+  float f1;
+  int32_t ifmin, ifmax;
+  float fstep;
+  int32_t shift1, lagmin, lagmax, lagstep;
+  float drift1;
+  int32_t symfac;
+  int32_t mode;
+} uwspr_sync_call;
+typedef struct uwspr_sync_result {
+  float sync;
+  int32_t shift1;
+  float f1;
+  uint8_t symbols[UWSPR_NSYM];
+  uint8_t _pad[2];
+} uwspr_sync_result;
+int uwspr_sync_and_demodulate_batch(uwspr_ctx *ctx, const float *frames, int B,
+                                    int where, const uwspr_sync_call *calls,
+                                    int ncalls, uwspr_sync_result *results);
+
+/* ---- refinement schedule: sync_and_demodulate_impl::demodulate ---------- */
+/* cands [B][cand_stride], npk [B] as produced by uwspr_fdr_batch; the first
+ * min(npk[b], max_per_frame) candidates of each frame are refined.
+ * out [B][max_per_frame]; entries past npk[b] are zeroed. */
+int uwspr_demod_batch(uwspr_ctx *ctx, const float *frames, int B, int where,
+                      const uwspr_candidate *cands, const int32_t *npk,
+                      int cand_stride, int max_per_frame, uwspr_demod_out *out);
+
+/* FDR followed by the schedule with candidates kept in HBM in between (the
+ * FDR -> sync_and_demodulate PDU hop of the flowgraph, examples/
+ * WaveFilePlusNoiseDecode.grc).  Any output pointer may be NULL. */
+int uwspr_pipeline_batch(uwspr_ctx *ctx, const float *frames, int B, int where,
+                         int max_per_frame, uwspr_candidate *cands,
+                         int32_t *npk, uwspr_demod_out *out);
+
+/* ---- measurement -------------------------------------------------------- */
+enum { UWSPR_K_SPECTROGRAM = 0, UWSPR_K_SPECTRUM = 1, UWSPR_K_COARSE = 2,
+       UWSPR_K_TONECORR = 3, UWSPR_K_FOLD = 4, UWSPR_K_SCHED = 5, UWSPR_K_COUNT = 6 };
+typedef struct uwspr_prof {
+  double ms[UWSPR_K_COUNT];        /* summed HIP-event time per kernel family */
+  int64_t launches[UWSPR_K_COUNT];
+  int64_t units[UWSPR_K_COUNT];    /* frames (K0,K1), candidates (K2), hypotheses (K3,K4) */
+} uwspr_prof;
+/* HIP events are recorded around every kernel launch on the context's stream
+ * while enabled; uwspr_prof_read synchronises, sums and resets them. */
+int uwspr_prof_enable(uwspr_ctx *ctx, int on);
+int uwspr_prof_read(uwspr_ctx *ctx, uwspr_prof *out);
+
+/* ---- host-side tail of the path ------------------ */
+/* sync_and_demodulate_impl.cc:265-282 */
+void uwspr_deinterleave(uint8_t *symbols162);
+/* lib/Fano.cc:110-252 with the block's metric table (Fano.cc:36-45).
+ * returns 0 decoded, -1 timeout (same as the reference). data: 11 bytes. */
+int uwspr_fano_decode(const uint8_t *symbols162, uint8_t *data11,
+                      uint32_t *metric, uint32_t *cycles, uint32_t *maxnp,
+                      int delta, uint32_t maxcycles);
+/* lib/Fano.cc:81-100 */
+int uwspr_fano_encode(uint8_t *symbols, const uint8_t *data, uint32_t nbytes);
+/* Replays cc:457-490 for one candidate on a uwspr_demod_out: gates, deinterleave,
+ * Fano in reference order.  returns 1 and fills message7 on decode, else 0. */
+int uwspr_decode_candidate(const uwspr_demod_out *d, int8_t *message7,
+                           int32_t *idt_used);
+/* lib/helpers.cc unpk_ (called at WSPR_unpacker_impl.cc:129), without the
+ * on-disk hash table: "CALL GRID dBm" into out (>= 23 bytes). returns 0 ok. */
+int uwspr_unpack_message(const int8_t *message7, char *out, size_t out_len);
+/* .c2 reader, lib/c2file_source_impl.cc:80-96 (Q negated on load).
+ * iq: 2*45000 floats. */
+int uwspr_c2_read(const char *path, float *iq, double *dial_freq, int32_t *type);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UWSPR_HIP_H */

@@ -1,0 +1,269 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs, and against the committed golden vectors.  Integer / byte /
+index fields bit-exact; float metrics within 1e-5 relative (north_star), and in
+practice bit-exact except where noted (log10, binary64 sin/cos libraries).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5   # BASELINE.json north_star tolerance for float metrics
+
+
+@pytest.fixture(scope="module")
+def ctx(G):
+    c = G.Context()
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def frames(G):
+    return G.synth.make_frames(4, seed=0xC0FFEE, snr_db=-20.0)
+
+
+@pytest.fixture(scope="module")
+def vec():
+    return np.load(os.path.join(GOLDEN, "oracle_vectors.npz"))
+
+
+def cand_equal(a, b, lin_strict=True):
+    """Compare the fields the PDU carries (FDR_impl.cc:414-455)."""
+    assert int(a["m_type"]) == int(b["m_type"])
+    assert int(a["shift"]) == int(b["shift"])
+    assert np.float32(a["freq"]).tobytes() == np.float32(b["freq"]).tobytes()
+    assert abs(float(a["sync"]) - float(b["sync"])) <= RTOL * abs(float(b["sync"]))
+    assert abs(float(a["snr"]) - float(b["snr"])) <= RTOL * abs(float(b["snr"])) + 1e-6
+    if int(a["m_type"]) == 0:
+        da = np.frombuffer(a.tobytes()[24:28], np.float32)[0]
+        db = np.frombuffer(b.tobytes()[24:28], np.float32)[0]
+        assert da == db
+    else:
+        for k in ("V1", "V2", "p1", "p2"):
+            assert a[k] == b[k]
+
+
+def test_info_matches_reference_constants(ctx):
+    i = ctx.info
+    assert (i.size, i.m, i.hpbm, i.n, i.finpb, i.noiseidx) == (512, 256, 14, 348, 28, 8)
+    assert i.df == 0.732421875 and i.cell_hyps == 126
+    assert i.device_name.decode().startswith("gfx950")
+
+
+def test_spectrogram_and_stats_bit_exact(ctx, oracle, frames):
+    """K1 + K2 vs the oracle: ps tile, psavg, smspec, noise (rows a3, a4)."""
+    ctx.fdr_batch(frames)
+    ps, psavg, smraw, smspec, noise = ctx.fdr_spectrum(frames.shape[0])
+    f = oracle.FDR()
+    lo, w = ctx.info.band_lo, ctx.info.band_w
+    for b in range(frames.shape[0]):
+        ops = f.spectrogram(frames[b])
+        assert ps[b].tobytes() == ops[:, lo:lo + w].tobytes()
+        opsavg, osmraw, osmspec, onoise = f.stats(ops)
+        assert psavg[b].tobytes() == opsavg[lo:lo + w].tobytes()
+        assert smraw[b].tobytes() == osmraw.tobytes()
+        assert smspec[b].tobytes() == osmspec.tobytes()
+        assert np.float32(noise[b]).tobytes() == np.float32(onoise).tobytes()
+
+
+def test_fdr_candidates_match_oracle(ctx, oracle, frames):
+    """rows a5-a11: candidate lists, order, selection."""
+    got = ctx.fdr_batch(frames)
+    f = oracle.FDR()
+    for b in range(frames.shape[0]):
+        exp = f.transform(frames[b])
+        assert len(got[b]) == len(exp) > 0
+        for a, e in zip(got[b], exp):
+            cand_equal(a, e)
+
+
+def test_fdr_candidates_match_committed_vectors(ctx, frames, vec):
+    got = ctx.fdr_batch(frames)
+    for b in range(frames.shape[0]):
+        n = int(vec["npk"][b])
+        assert len(got[b]) == n
+        for a, e in zip(got[b], vec["cands"][b, :n]):
+            cand_equal(a, e)
+
+
+def test_fdr_syncgrid_bit_exact(ctx, oracle, frames, vec):
+    """rows a6-a10: every one of the 16380 hypothesis metrics of candidate 0."""
+    ctx.keep_syncgrid(1)
+    try:
+        ctx.fdr_batch(frames)
+        grid = ctx.fdr_syncgrid(frames.shape[0])
+    finally:
+        ctx.keep_syncgrid(0)
+    assert grid.shape[2:] == (5, 26, 126)
+    for b in range(frames.shape[0]):
+        assert grid[b, 0].tobytes() == vec["grid0"][b].tobytes()
+
+
+def test_ve3emb_known_answers_on_gpu(ctx, G, ve3emb):
+    known = json.load(open(os.path.join(GOLDEN, "ve3emb_known.json")))
+    cands, out = ctx.pipeline_batch(ve3emb[None], max_per_frame=1)
+    c = cands[0][0]
+    assert len(cands[0]) == known["npk"] and int(c["m_type"]) == known["m_type"]
+    assert float(c["freq"]) == known["freq"] and int(c["shift"]) == known["shift"]
+    assert (float(c["V1"]), float(c["V2"]), int(c["p1"]), int(c["p2"])) == (-1.0, -1.0, 0, 650)
+    assert "%.9f" % c["sync"] == "%.9f" % known["sync"]
+    dec = G.decode_candidate(out[0, 0])
+    assert dec is not None
+    msg, idt = dec
+    assert bytes(msg.view(np.uint8)).hex() == known["blob_hex"]
+    assert G.unpack_message(msg) == (0, known["message"])
+
+
+def test_fdr_linear_drift_grid_and_threshold(G, oracle, frames):
+    """maxdrift > 0 (linear sweep, row a7) and a threshold that disables SLM wins."""
+    for kw in ({"maxdrift": 2}, {"threshold": 1000000}, {"halfbandwidth": 40, "maxdrift": 1}):
+        c = G.Context(**kw)
+        try:
+            got = c.fdr_batch(frames[:2])
+        finally:
+            c.close()
+        f = oracle.FDR(**kw)
+        for b in range(2):
+            exp = f.transform(frames[b])
+            assert len(got[b]) == len(exp)
+            for a, e in zip(got[b], exp):
+                cand_equal(a, e)
+
+
+def test_sync_sweep_config3_grid(ctx, G, oracle, frames, vec):
+    """rows a13/a14: 2 frames x 200 (freq, lag, drift) hypotheses, soft symbols
+    byte-exact, sync within tolerance (committed vectors + live oracle spot check)."""
+    hy = vec["sweep_hyps"]
+    sync, sym = ctx.sync_sweep(frames, hy, soft=True)
+    assert (sym == vec["sweep_symbols"]).all()
+    np.testing.assert_allclose(sync, vec["sweep_sync"], rtol=RTOL, atol=0)
+    assert sync.tobytes() == vec["sweep_sync"].tobytes()  # in practice bit-exact
+    lin = np.zeros(1, oracle.CAND_DTYPE)[0]
+    for q in (0, 57, 399):
+        h = hy[q]
+        s, _, _, y = oracle.sync_and_demodulate(lin, 1500, frames[h["frame"]], float(h["f0"]), 0, 0,
+                                                0.0, int(h["lag"]), 0, 0, 1, float(h["drift"]), 50, 2)
+        assert (y == sym[q]).all() and np.float32(s).tobytes() == sync[q].tobytes()
+
+
+def test_sync_sweep_edges(ctx, G, oracle, frames):
+    """lags that run off either end of the frame (n<=0 and n>=np are skipped,
+    cc:205), nonlinear hypotheses, skipped (frame<0) entries, odd batch sizes."""
+    N = G.native
+    hy = np.zeros(9, N.HYP_DTYPE)
+    hy["frame"] = [0, 0, 1, 1, -1, 2, 3, 3, 3]
+    hy["lag"] = [-300, -1, 0, 3600, 100, 3528, 1, 368, 5000]
+    hy["f0"] = [0.5, -0.25, 0.0, 1.0, 0.0, -1.5, 0.1, 0.0, 2.0]
+    hy["drift"] = [0.0, 0.5, -1.0, 0.0, 0.0, 2.0, 0.0, 0.0, -0.5]
+    hy["m_type"][6] = 1; hy["V1"][6] = -2.0; hy["V2"][6] = 1.0; hy["p2"][6] = 250
+    hy["m_type"][7] = 1; hy["V1"][7] = 1.0; hy["V2"][7] = 2.0; hy["p2"][7] = 50
+    sync, sym = ctx.sync_sweep(frames, hy, soft=True)
+    for q, h in enumerate(hy):
+        if h["frame"] < 0:
+            assert sync[q] == np.float32(-1e30) and not sym[q].any()
+            continue
+        cand = np.zeros(1, oracle.CAND_DTYPE)[0]
+        cand["m_type"] = h["m_type"]; cand["V1"] = h["V1"]; cand["V2"] = h["V2"]
+        cand["p1"] = h["p1"]; cand["p2"] = h["p2"]
+        s, _, _, y = oracle.sync_and_demodulate(cand, 1500, frames[h["frame"]], float(h["f0"]), 0, 0,
+                                                0.0, int(h["lag"]), 0, 0, 1, float(h["drift"]), 50, 2)
+        assert (y == sym[q]).all(), q
+        assert np.float32(s).tobytes() == sync[q].tobytes(), q
+
+
+def test_sync_and_demodulate_calls_read_like_the_reference(ctx, G, oracle, frames, vec):
+    """Argument-for-argument form of sync_and_demodulate() (cc:126-131), modes 0/1/2."""
+    N = G.native
+    cands = vec["cands"]
+    calls = np.zeros(6, N.CALL_DTYPE)
+    specs = [  # frame, f1, ifmin, ifmax, fstep, shift1, lagmin, lagmax, lagstep, drift1, mode
+        (0, float(cands[0, 0]["freq"]), 0, 0, 0.0, 256, 128, 384, 64, 0.0, 0),
+        (0, float(cands[0, 0]["freq"]), -2, 2, 0.25, 320, 0, 0, 64, 0.0, 1),
+        (1, 0.1, -2, 2, 0.05, 368, 0, 0, 16, 0.5, 1),
+        (2, float(cands[2, 0]["freq"]), 0, 0, 0.0, 300, 268, 332, 16, -0.5, 0),
+        (3, -0.3, 0, 0, 0.0, 360, 0, 0, 16, 0.0, 2),
+        (3, 0.0, -1, 3, 0.1, 368, 0, 0, 8, 1.0, 1),
+    ]
+    for q, s in enumerate(specs):
+        c = calls[q]
+        c["frame"], c["f1"], c["ifmin"], c["ifmax"], c["fstep"], c["shift1"] = s[:6]
+        c["lagmin"], c["lagmax"], c["lagstep"], c["drift1"], c["mode"] = s[6:]
+        c["symfac"] = 50
+    res = ctx.sync_and_demodulate(frames, calls)
+    lin = np.zeros(1, oracle.CAND_DTYPE)[0]
+    for q, s in enumerate(specs):
+        sy, sh, f1, y = oracle.sync_and_demodulate(lin, 1500, frames[s[0]], s[1], s[2], s[3], s[4],
+                                                   s[5], s[6], s[7], s[8], s[9], 50, s[10])
+        assert np.float32(sy).tobytes() == res[q]["sync"].tobytes()
+        if s[10] <= 1:
+            assert sh == res[q]["shift1"] and np.float32(f1).tobytes() == res[q]["f1"].tobytes()
+        else:
+            assert (y == res[q]["symbols"]).all()
+
+
+def test_schedule_matches_oracle(ctx, oracle, frames, vec):
+    """row a15: the S0..S5 refinement schedule, every candidate of every frame."""
+    cands = [vec["cands"][b, :int(vec["npk"][b])] for b in range(4)]
+    per = max(len(c) for c in cands)
+    out = ctx.demod_batch(frames, cands, max_per_frame=per)
+    for b in range(4):
+        for j in range(len(cands[b])):
+            d = oracle.demod_candidate(cands[b][j], 1500, frames[b])
+            o = out[b, j]
+            assert int(o["worth_a_try"]) == d["worth_a_try"] and int(o["shift1"]) == d["shift1"]
+            for k in ("f1", "drift1", "sync1"):
+                assert np.float32(o[k]).tobytes() == np.float32(d[k]).tobytes(), (b, j, k)
+            if d["worth_a_try"]:
+                assert (o["symbols"] == d["symbols"]).all()
+                assert (o["jig_shift"] == d["jig_shift"]).all()
+                assert o["jig_sync"].tobytes() == d["jig_sync"].tobytes()
+                assert o["jig_rms"].tobytes() == d["jig_rms"].tobytes()
+        for j in range(len(cands[b]), per):
+            assert int(out[b, j]["worth_a_try"]) == 0 and not out[b, j]["symbols"].any()
+    assert (out[:, 0]["symbols"] == vec["demod_symbols"]).all()
+
+
+def test_pipeline_device_pointers_equal_host_pointers(ctx, G, frames):
+    """The same batch through UWSPR_DEVICE pointers (HBM-resident, what bench.py times)."""
+    import torch
+    dev = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    c1, o1 = ctx.pipeline_batch(frames, max_per_frame=2)
+    c2, o2 = ctx.pipeline_batch(dev, max_per_frame=2)
+    for a, b in zip(c1, c2):
+        assert a.tobytes() == b.tobytes()
+    assert o1.tobytes() == o2.tobytes()
+
+
+def test_full_size_properties_256_frames(ctx, G):
+    """BASELINE configs[1] size: 256 frames.  Size-independent properties:
+    (1) batch result == per-frame result (frames are independent),
+    (2) every -20 dB frame decodes back to the bits it was generated from."""
+    frames, meta = G.synth.make_frames(256, seed=77, snr_db=-20.0, return_meta=True)
+    cands, out = ctx.pipeline_batch(frames, max_per_frame=1)
+    idx = [0, 31, 128, 255]
+    for b in idx:
+        c1, o1 = ctx.pipeline_batch(frames[b:b + 1], max_per_frame=1)
+        assert c1[0].tobytes() == cands[b].tobytes() and o1[0].tobytes() == out[b].tobytes()
+    ok = 0
+    for b in range(256):
+        dec = G.decode_candidate(out[b, 0])
+        if dec is not None:
+            bits = np.unpackbits(dec[0].view(np.uint8))[:50]
+            ok += int((bits == meta[b]["bits"]).all())
+    assert ok >= 250, ok
+
+
+def test_context_rejects_bad_parameters(G):
+    N = G.native
+    with pytest.raises(N.UwsprError) as e:
+        G.Context(halfbandwidth=188)
+    assert e.value.status == -1          # reference exit(-1)s, FDR_impl.cc:85-90
+    with pytest.raises(N.UwsprError) as e:
+        G.Context(halfbandwidth=187)     # GRC XML default: the reference reads out of bounds
+    assert e.value.status == -2
