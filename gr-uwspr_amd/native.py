@@ -55,11 +55,14 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     deps.append(os.path.join(_HERE, "..", "include", "uwspr_hip.h"))
-    if force or _stale(LIBPATH, deps):
-        cmd = [_hipcc()] + HIPFLAGS + ["-shared"] + srcs + ["-o", LIBPATH]
+    cmd = [_hipcc()] + HIPFLAGS + ["-shared"] + srcs + ["-o", LIBPATH]
+    stamp = LIBPATH + ".cmd"
+    same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
+    if force or not same_cmd or _stale(LIBPATH, deps):
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
+        open(stamp, "w").write(" ".join(cmd))
     hostdir = os.path.join(_HERE, "host")
     hsrcs = [os.path.join(hostdir, f) for f in sorted(os.listdir(hostdir)) if f.endswith(".cc")] \
         if os.path.isdir(hostdir) else []
