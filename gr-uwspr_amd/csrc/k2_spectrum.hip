@@ -69,7 +69,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_spectrum(
 
   // SNR in linear form and floor (cc:287-291)
   for (int j = tid; j < f.finpb; j += K2_THREADS) {
-    float v = (float)((double)__fdiv_rn(sm[j], noise) - 1.0);
+    float v = (float)((double)ieee_divf(sm[j], noise) - 1.0);
     if (v < f.min_snr) v = f.min_snr_floor;
     sm[j] = v;   // each thread rewrites only its own slots
     smspec_g[(size_t)b * f.finpb + j] = v;

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   uwspr_candidate *cand = cands + (size_t)b * f.maxfreqs + j;
   const float freq0 = cand->freq;
   // cc:341: if0 = freq/df + m (binary32), truncated
-  const int if0 = (int)(__fdiv_rn(freq0, f.df) + (float)f.m);
+  const int if0 = (int)(ieee_divf(freq0, f.df) + (float)f.m);
 
   // ---- stage the sqrt tile ------------------------------------------------
   const float *psb = ps + (size_t)b * f.n * f.band_w;
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   for (int idx = tid; idx < f.n * f.nc; idx += K3_THREADS) {
     int row = idx / f.nc, ci = idx - row * f.nc;
     const float *pr = psb + (size_t)row * f.band_w + c0 + ci;
-    tile[idx] = make_float4(__fsqrt_rn(pr[-3]), __fsqrt_rn(pr[-1]), __fsqrt_rn(pr[1]),
-                            __fsqrt_rn(pr[3]));
+    tile[idx] = make_float4(ieee_sqrtf(pr[-3]), ieee_sqrtf(pr[-1]), ieee_sqrtf(pr[1]),
+                            ieee_sqrtf(pr[3]));
   }
   __syncthreads();
 
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
         }
       }
     }
-    syncbuf[g] = __fdiv_rn(ss, pw);  // cc:357,390
+    syncbuf[g] = ieee_divf(ss, pw);  // cc:357,390
   }
   __syncthreads();
 
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
       int start = 0;
       for (;;) {
         const bool pred = in && tid >= start &&
-                          (lin ? (v > best) : (__fdiv_rn(v, best) > f.threshold));
+                          (lin ? (v > best) : (ieee_divf(v, best) > f.threshold));
         const unsigned long long mask = __ballot(pred);
         if (mask == 0ull) break;
         const int first = __ffsll((long long)mask) - 1;

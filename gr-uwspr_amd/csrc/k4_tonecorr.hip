@@ -159,10 +159,10 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
 
   if (g0 + lane < total) {
     float4 p;
-    p.x = __fsqrt_rn(inp[0] * inp[0] + quad[0] * quad[0]);  // cc:211
-    p.y = __fsqrt_rn(inp[1] * inp[1] + quad[1] * quad[1]);
-    p.z = __fsqrt_rn(inp[2] * inp[2] + quad[2] * quad[2]);
-    p.w = __fsqrt_rn(inp[3] * inp[3] + quad[3] * quad[3]);
+    p.x = ieee_sqrtf(inp[0] * inp[0] + quad[0] * quad[0]);  // cc:211
+    p.y = ieee_sqrtf(inp[1] * inp[1] + quad[1] * quad[1]);
+    p.z = ieee_sqrtf(inp[2] * inp[2] + quad[2] * quad[2]);
+    p.w = ieee_sqrtf(inp[3] * inp[3] + quad[3] * quad[3]);
     if (!own_ok) p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     p_out[g0 + lane] = p;
   }

@@ -47,15 +47,15 @@ __global__ __launch_bounds__(256) void k5_fold(const dev_hyp *__restrict__ hyps,
       f2sum = (float)((double)f2sum + (double)(fs * fs) / 162.0);               // cc:244
     }
   }
-  sync[h] = __fdiv_rn(ss, totp);  // cc:226
+  sync[h] = ieee_divf(ss, totp);  // cc:226
   if (soft) {
-    const float fac = __fsqrt_rn(f2sum - fsum * fsum);  // cc:246
+    const float fac = ieee_sqrtf(f2sum - fsum * fsum);  // cc:246
     uint8_t *out = symbols + (size_t)h * UWSPR_NSYM;
     for (int i = 0; i < UWSPR_NSYM; i++) {
       const float4 P = ph[i];
       const bool bit = pr3_rt(i);
       float v = bit ? P.w - P.y : P.z - P.x;
-      v = __fdiv_rn(symfac * v, fac);  // cc:248
+      v = ieee_divf(symfac * v, fac);  // cc:248
       if (v > 127.0f) v = 127.0f;
       if (v < -128.0f) v = -128.0f;
       v = v + 128.0f;

@@ -19,6 +19,13 @@ __host__ __device__ constexpr uint32_t pr3_word(int w) {
 }
 __host__ __device__ constexpr int pr3_bit(int k) { return (pr3_word(k >> 5) >> (k & 31)) & 1; }
 
+// IEEE-754 correctly rounded binary32 sqrt and divide.  NOTE: HIP's __fsqrt_rn /
+// __fdiv_rn are NOT that (they lower to the 1-ulp native forms unless
+// OCML_BASIC_ROUNDED_OPERATIONS is defined); plain sqrtf() and `/` are, under
+// -fhip-fp32-correctly-rounded-divide-sqrt (set explicitly in the build flags).
+__device__ __forceinline__ float ieee_sqrtf(float x) { return __builtin_sqrtf(x); }
+__device__ __forceinline__ float ieee_divf(float x, float y) { return x / y; }
+
 // fine-grid hypothesis as the kernels consume it (24 B)
 struct dev_hyp {
   int32_t frame;   // <0: skip

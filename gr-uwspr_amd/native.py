@@ -21,7 +21,7 @@ HOSTLIB = os.path.join(LIBDIR, "libuwspr_blocks.so")
 SOURCES = ["uwspr_api.hip", "k1_spectrogram.hip", "k2_spectrum.hip", "k3_coarse.hip",
            "k4_tonecorr.hip", "k5_fold_schedule.hip", "host_tail.cpp"]
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-            "-fno-slp-vectorize", "-fPIC", "-Wall", "-Wno-unused-function"]
+            "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 NSYM, NSLM, NK0, NIFR, NJIG = 162, 125, 26, 5, 17
 HOST, DEVICE = 0, 1
