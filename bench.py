@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the coarse (FDR) + fine (sync_and_demodulate) path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the whole hot path (K1 spectrogram, K2 spectrum/peaks,
+K3 coarse search + selection over ALL candidates, then the S0..S5 refinement
+schedule incl. the 17 soft-symbol vectors for the top candidate of every frame)
+over one batch of synthetic frames that is already resident in HBM, followed by
+the gather of the per-frame candidate slabs to rank 0.  Workload = BASELINE.json
+configs[1]: 256 synthetic 375 Hz / 45000-sample frames per GPU at -20 dB, flowgraph
+default FDR grid, single candidate per frame.  For N>1 every rank runs its own
+256 frames (weak scaling); frames shard with no data-path collective.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      the dominant kernel (K4 tone correlation sweep): algorithmic
+                bytes/launch (331950 B per hypothesis) / HIP-event
+                time per launch, against the 8 TB/s HBM peak.
+  cpu_baseline  the CPU restatement (oracle/, kind "port") on a bounded sample
+                of the same workload on this box's host cores.
+  kernels       HIP-event time per kernel family per step.
+  sweep         (N=1) BASELINE configs[2]: 1024 frames x 200 (freq,lag,drift)
+                hypotheses through uwspr_sync_sweep, the north_star's roofline case.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HYP_BYTES = 162 * 256 * 8 + 162 + 12      # 331950 B per fine hypothesis
+HYP_FLOP = 162 * 4 * 256 * 14             # binary32 ops per hypothesis in K4
+HBM_PEAK_GBS = 8000.0
+FP32_NOFMA_PEAK_TOPS = 78.6               # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one op/lane/clk
+
+
+def cpu_baseline(frames_np, budget_s=20.0):
+    """Oracle (CPU restatement) on a bounded sample: FDR over all candidates +
+    the schedule for the top candidate, one frame per worker thread (the C code
+    is re-entrant and ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle_py as O
+    O.lib()
+    O.pr3()
+    ncores = max(1, min(16, len(os.sched_getaffinity(0))))
+    fdrs = [O.FDR() for _ in range(ncores)]
+
+    def one(args):
+        w, b = args
+        c = fdrs[w].transform(frames_np[b])
+        if len(c):
+            O.demod_candidate(c[0], 1500, frames_np[b])
+        return 1
+
+    t0 = time.time()
+    one((0, 0))
+    per = max(time.time() - t0, 1e-3)
+    n = int(max(ncores, min(frames_np.shape[0], budget_s * ncores / per)))
+    n = min(n, frames_np.shape[0])
+    t0 = time.time()
+    with ThreadPoolExecutor(ncores) as ex:
+        list(ex.map(one, [(i % ncores, i) for i in range(n)]))
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": ncores, "kind": "port",
+            "sample": "%d of the benchmark's frames, oracle FDR (all candidates) + S0..S5 "
+                      "schedule (17 soft-symbol vectors) for the top candidate, %d threads, %.1f s"
+                      % (n, ncores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--snr", type=float, default=-20.0)
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sweep-frames", type=int, default=1024)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import gr_uwspr_amd as G
+    from gr_uwspr_amd import dist as D
+    N = G.native
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.frames
+    frames = G.synth.make_frames_torch(B, dev, seed=0xC0FFEE + 7919 * rank, snr_db=args.snr)
+    ctx = G.Context(device=local)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    cands_t = torch.empty(B * ctx.maxfreqs * 48, dtype=torch.uint8, device=dev)
+    npk_t = torch.empty(B, dtype=torch.int32, device=dev)
+    out_t = torch.empty(B * N.DEMOD_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+
+    def step():
+        ctx.pipeline_batch_into(frames, cands_t, npk_t, out_t, max_per_frame=1)
+        slab = D.pack_slabs(cands_t, npk_t, out_t, ctx.maxfreqs, 1, N.DEMOD_DTYPE.itemsize)
+        return D.gather_slabs(slab, dst=0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.prof_enable(True)
+    ctx.prof_read()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.prof_read()
+    ctx.prof_enable(False)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- what the batch contained (outside the timed region) ----------------
+    cands = np.frombuffer(cands_t.cpu().numpy().tobytes(), N.CAND_DTYPE).reshape(B, -1)
+    npk = npk_t.cpu().numpy()
+    out = np.frombuffer(out_t.cpu().numpy().tobytes(), N.DEMOD_DTYPE).reshape(B, 1)
+    top_lin = np.array([cands[b, 0]["m_type"] == 0 if npk[b] > 0 else False for b in range(B)])
+    live = npk > 0
+    worth = out[:, 0]["worth_a_try"] > 0
+    fine_hyps = int(10 * live.sum() + 2 * (live & top_lin).sum() + 27 * worth.sum())
+    decoded = 0
+    for b in range(min(B, 64)):
+        decoded += 1 if G.decode_candidate(out[b, 0]) is not None else 0
+
+    frames_cpu = frames.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu) else None
+    result = None
+    if rank == 0:
+        k4 = prof["tonecorr"]
+        k4_launch_ms = k4["ms"] / max(k4["launches"], 1)
+        k4_bytes_per_launch = fine_hyps * HYP_BYTES / 6.0      # 6 K4 launches per step
+        achieved = (fine_hyps * HYP_BYTES * args.steps) / (k4["ms"] * 1e-3) / 1e9 if k4["ms"] > 0 else 0.0
+        kern = {k: {"ms_per_step": v["ms"] / args.steps, "launches_per_step": v["launches"] / args.steps}
+                for k, v in prof.items()}
+        result = {
+            "metric": "2-min WSPR frames decoded/sec (coarse+sync)",
+            "value": world * B * args.steps / dt,
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d synthetic .c2 frames (375 Hz, 45000 samples, "
+                                   "SNR %.0f dB) per GPU, flowgraph-default FDR grid (hbw=10, maxdrift=0, "
+                                   "threshold=10, all candidates searched), S0..S5 schedule + 17 soft-symbol "
+                                   "vectors for the top candidate of each frame, slab gather to rank 0"
+                                   % (B, args.snr),
+                       "frames_per_gpu": B, "candidates_per_frame_mean": float(npk.mean()),
+                       "fine_hypotheses_per_step": fine_hyps,
+                       "coarse_hypotheses_per_step": int(npk.sum()) * 130 * ctx.info.cell_hyps,
+                       "top_candidate_decodes_in_first_64": decoded, "parallelism": "dp%d" % world},
+            "roofline": {"kernel": "k4_tonecorr", "bound": "hbm", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "bytes_per_launch_algorithmic": k4_bytes_per_launch,
+                         "avg_launch_ms": k4_launch_ms,
+                         "fp32_tops": fine_hyps * HYP_FLOP * args.steps / (k4["ms"] * 1e-3) / 1e12 if k4["ms"] > 0 else 0.0,
+                         "fp32_nofma_peak_tops": FP32_NOFMA_PEAK_TOPS},
+            "kernels": kern,
+        }
+
+    # ---- configs[2]: the (freq, lag, drift) sweep, N=1 only -----------------
+    if rank == 0 and world == 1 and not args.no_sweep:
+        Bs = args.sweep_frames
+        del frames
+        torch.cuda.empty_cache()
+        fr2 = G.synth.make_frames_torch(Bs, dev, seed=99, snr_db=args.snr)
+        hy = G.sweep_grid_uniform(Bs, f_c=0.0, shift_c=368)
+        H = hy.size
+        hy_t = torch.from_numpy(np.frombuffer(hy.tobytes(), np.uint8).copy()).to(dev)
+        sync_t = torch.empty(H, dtype=torch.float32, device=dev)
+        sym_t = torch.empty(H * 162, dtype=torch.uint8, device=dev)
+        ctx.sync_sweep_into(fr2, hy_t, H, sync_t, sym_t)
+        torch.cuda.synchronize()
+        ctx.prof_enable(True)
+        ctx.prof_read()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.sync_sweep_into(fr2, hy_t, H, sync_t, sym_t)
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - t0) / reps
+        p2 = ctx.prof_read()
+        ctx.prof_enable(False)
+        k4ms = p2["tonecorr"]["ms"] / reps
+        result["sweep"] = {
+            "workload": "BASELINE configs[2]: %d frames x 200 (freq,lag,drift) hypotheses, sync + 162 soft symbols each" % Bs,
+            "hypotheses": H, "ms_total": 1e3 * dts, "k4_ms": k4ms,
+            "k5_ms": p2["fold"]["ms"] / reps,
+            "hyps_per_s": H / dts,
+            "algorithmic_GBs_k4": H * HYP_BYTES / (k4ms * 1e-3) / 1e9,
+            "frac_of_hbm_peak_k4": H * HYP_BYTES / (k4ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "fp32_tops_k4": H * HYP_FLOP / (k4ms * 1e-3) / 1e12,
+            "north_star_bar_ms": 28.3,
+        }
+
+    if rank == 0:
+        result["cpu_baseline"] = cpu_baseline(frames_cpu) if frames_cpu is not None else None
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -191,6 +191,26 @@ class Context:
                                                   C.c_void_p(out.ctypes.data)))
         return [cands[b, :npk[b]].copy() for b in range(B)], out.copy()
 
+    def pipeline_batch_into(self, frames, cands_t, npk_t, out_t, max_per_frame=1):
+        """Device-resident form used by bench.py: frames and the three output
+        buffers are torch CUDA tensors; nothing is copied to the host and the call
+        returns as soon as the work is enqueued on the context's stream."""
+        p, B, where, keep = self._frames(frames)
+        assert where == N.DEVICE
+        assert cands_t.numel() * cands_t.element_size() >= B * self.maxfreqs * 48
+        assert out_t.numel() * out_t.element_size() >= B * max_per_frame * N.DEMOD_DTYPE.itemsize
+        self._chk(self.L.uwspr_pipeline_batch(self.h, p, B, where, max_per_frame,
+                                              C.c_void_p(cands_t.data_ptr()),
+                                              C.c_void_p(npk_t.data_ptr()),
+                                              C.c_void_p(out_t.data_ptr())))
+
+    def sync_sweep_into(self, frames, hyps_t, H, sync_t, sym_t):
+        p, B, where, keep = self._frames(frames)
+        assert where == N.DEVICE
+        self._chk(self.L.uwspr_sync_sweep(self.h, p, B, C.c_void_p(hyps_t.data_ptr()), H, where,
+                                          C.c_void_p(sync_t.data_ptr()),
+                                          C.c_void_p(sym_t.data_ptr()) if sym_t is not None else None))
+
     # -- measurement -------------------------------------------------------
     def prof_enable(self, on=True):
         self._chk(self.L.uwspr_prof_enable(self.h, 1 if on else 0))
