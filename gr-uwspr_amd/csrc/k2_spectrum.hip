@@ -21,7 +21,9 @@ constexpr int K2_MAXV = 512;  // >= band_w and >= finpb
 __global__ __launch_bounds__(K2_THREADS) void k2_spectrum(
     const float *__restrict__ ps, fdr_consts f, float *__restrict__ psavg_g,
     float *__restrict__ smraw_g, float *__restrict__ smspec_g, float *__restrict__ noise_g,
-    uwspr_candidate *__restrict__ cands, int32_t *__restrict__ npk_g) {
+    uwspr_candidate *__restrict__ cands, int32_t *__restrict__ npk_g, int stage_lds,
+    int32_t *__restrict__ work_count, int32_t *__restrict__ work_list) {
+  extern __shared__ float ps_s[];  // [n][band_w] when stage_lds
   __shared__ float psavg[K2_MAXV];
   __shared__ float sm[K2_MAXV];
   __shared__ int flag[K2_MAXV];
@@ -34,12 +36,35 @@ __global__ __launch_bounds__(K2_THREADS) void k2_spectrum(
   const float *psb = ps + (size_t)b * f.n * f.band_w;
   if (tid == 0) noise_s = __builtin_nanf("");  // stays NaN only if the frame holds NaNs
 
-  // psavg over the kept columns, rows ascending (cc:257-263)
-  for (int col = tid; col < f.band_w; col += K2_THREADS) {
-    float acc = 0.0f;
-    for (int i = 0; i < f.n; i++) acc = acc + psb[(size_t)i * f.band_w + col];
-    psavg[col] = acc;
-    psavg_g[(size_t)b * f.band_w + col] = acc;
+  // psavg over the kept columns, rows ascending (cc:257-263).  The column sums
+  // are serial in the row index, so the frame's tile is first brought into LDS
+  // with all 256 threads (coalesced), then one thread per column adds it up.
+  if (stage_lds) {
+    const int tot = f.n * f.band_w;
+    for (int e = tid; e < tot; e += K2_THREADS) ps_s[e] = psb[e];
+    __syncthreads();
+    for (int col = tid; col < f.band_w; col += K2_THREADS) {
+      float acc = 0.0f;
+#pragma unroll 12
+      for (int i = 0; i < f.n; i++) acc = acc + ps_s[i * f.band_w + col];
+      psavg[col] = acc;
+      psavg_g[(size_t)b * f.band_w + col] = acc;
+    }
+  } else {
+    for (int col = tid; col < f.band_w; col += K2_THREADS) {
+      float acc = 0.0f;
+      int i = 0;
+      for (; i + 12 <= f.n; i += 12) {
+        float v[12];
+#pragma unroll
+        for (int q = 0; q < 12; q++) v[q] = psb[(size_t)(i + q) * f.band_w + col];
+#pragma unroll
+        for (int q = 0; q < 12; q++) acc = acc + v[q];
+      }
+      for (; i < f.n; i++) acc = acc + psb[(size_t)i * f.band_w + col];
+      psavg[col] = acc;
+      psavg_g[(size_t)b * f.band_w + col] = acc;
+    }
   }
   __syncthreads();
 
@@ -111,12 +136,21 @@ __global__ __launch_bounds__(K2_THREADS) void k2_spectrum(
     c.m_nonlinear.V1 = 0.0; c.m_nonlinear.V2 = 0.0; c.m_nonlinear.p1 = 0; c.m_nonlinear.p2 = 0;
     out[rank] = c;
   }
+  // work list for the coarse search: one item per (frame, candidate)
+  if (tid == 0 && npk > 0) {
+    const int base = atomicAdd(work_count, npk);
+    for (int k = 0; k < npk; k++) work_list[base + k] = b * f.cand_slots + k;
+  }
 }
 
 void launch_spectrum(uwspr_ctx *c, int B) {
   prof_scope ps(c, UWSPR_K_SPECTRUM, B);
-  hipLaunchKernelGGL(k2_spectrum, dim3(B), dim3(K2_THREADS), 0, c->stream, c->d_ps, c->fc,
-                     c->d_psavg, c->d_smraw, c->d_smspec, c->d_noise, c->d_cands, c->d_npk);
+  const size_t tile = (size_t)c->fc.n * c->fc.band_w * sizeof(float);
+  const int stage = tile <= 60 * 1024;
+  (void)hipMemsetAsync(c->d_work, 0, sizeof(int32_t), c->stream);
+  hipLaunchKernelGGL(k2_spectrum, dim3(B), dim3(K2_THREADS), stage ? tile : 0, c->stream, c->d_ps,
+                     c->fc, c->d_psavg, c->d_smraw, c->d_smspec, c->d_noise, c->d_cands, c->d_npk,
+                     stage, c->d_work, c->d_work + 1);
 }
 
 }  // namespace uwspr

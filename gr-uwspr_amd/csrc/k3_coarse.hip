@@ -6,21 +6,29 @@
 // drifts + 125 straight-line trajectories) = 16380 hypotheses at the defaults,
 // each a 162-term sync-vector correlation over the spectrogram.
 //
-// Mapping (one 1024-thread workgroup per candidate):
-//  * the spectrogram window the candidate can touch is staged once into LDS as
+// What makes it cheap without changing a single result:
+//  * A hypothesis is fully described by its sequence of bin offsets ifd-ifr over
+//    the 162 symbols.  Those sequences are built once per context with the
+//    reference's exact expressions (cc:353 binary64 / cc:382-385 binary32) and
+//    DEDUPLICATED: at the defaults only 38 of the 126 per-cell sequences are
+//    distinct (the SLM reach is a few bins, so many trajectories quantise to the
+//    same path).  Identical sequences give bit-identical metrics, so each distinct
+//    one is evaluated once (130 x 38 = 4940 evaluations per candidate, not 16380)
+//    and the selection below reads it back through a hypothesis -> sequence map.
+//  * The spectrogram window the candidate can touch is staged once into LDS as
 //    float4 {sqrt ps[row][c-3], [c-1], [c+1], [c+3]} per (row, centre column c):
-//    one ds_read_b128 gather per symbol instead of four gathers + four sqrt;
-//  * the bin offsets ifd-ifr of every (ifr, hypothesis, symbol) come from a
-//    table built once per context with the reference's exact expressions
-//    (cc:353 double / cc:382-385 float), 4 symbols per 32-bit word, read
-//    coalesced across lanes;
-//  * one lane = one hypothesis, 162 sequential steps, so ss and pow accumulate
-//    in the reference's order (cc:207-209) and the metric is bit-identical;
-//  * all 16380 metrics stay in LDS; wave 0 then replays the reference's
-//    order-dependent running-best rule (strict > for linear cc:360, ratio
-//    against the running best for nonlinear cc:392) with ballots: a wave scans
-//    64 metrics per step and only serialises on acceptances.
+//    one ds_read_b128 gather per symbol instead of four gathers + four sqrt.
+//  * One lane = one (cell, sequence), 162 sequential steps, so ss and pow
+//    accumulate in the reference's order (cc:207-209): bit-identical metrics.
+//  * Wave 0 then replays the reference's ORDER-DEPENDENT running-best rule over
+//    all 16380 hypotheses in reference order (strict > for linear cc:360, ratio
+//    against the running best for nonlinear cc:392) with ballots: 64 hypotheses
+//    per step, serialising only on acceptances.
+// One 1024-thread workgroup per candidate; everything between the spectrogram
+// tile read and the 48-byte candidate record stays in LDS.
 // Roofline: LDS-gather / VALU bound; HBM traffic is the tile once (~60 KB).
+#include <algorithm>
+
 #include "uwspr_internal.h"
 
 #pragma clang fp contract(off)
@@ -29,22 +37,42 @@ namespace uwspr {
 
 constexpr int K3_THREADS = 1024;
 
-__global__ __launch_bounds__(K3_THREADS) void k3_coarse(
-    const float *__restrict__ ps, fdr_consts f, const uint32_t *__restrict__ off_tab,
-    uwspr_candidate *__restrict__ cands, const int32_t *__restrict__ npk,
-    float *__restrict__ syncgrid, int grid_cap) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  float4 *tile = reinterpret_cast<float4 *>(smem);                            // [n][nc]
-  float *syncbuf = reinterpret_cast<float *>(smem + (size_t)f.n * f.nc * 16); // [ntot]
+struct k3_lds_layout { size_t tile, uoff, sync, umap, total; };
+__host__ __device__ inline k3_lds_layout k3_layout(const fdr_consts &f) {
+  k3_lds_layout l;
+  l.tile = 0;
+  l.uoff = l.tile + (size_t)f.n * f.nc * 16;
+  l.sync = l.uoff + (size_t)UWSPR_NIFR * f.umax * 41 * 4;
+  l.umap = l.sync + (size_t)UWSPR_NIFR * UWSPR_NK0 * f.umax * 4;
+  l.total = l.umap + (((size_t)UWSPR_NIFR * f.cell_hyps * 2 + 15) & ~(size_t)15);
+  return l;
+}
 
-  const int b = blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
-  if (j >= npk[b]) return;  // workgroup-uniform
+__global__ __launch_bounds__(K3_THREADS) void k3_coarse(
+    const float *__restrict__ ps, fdr_consts f, const uint32_t *__restrict__ uoff_tab,
+    const uint16_t *__restrict__ umap_tab, uwspr_candidate *__restrict__ cands,
+    const int32_t *__restrict__ work, float *__restrict__ syncgrid, int grid_cap) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const k3_lds_layout lay = k3_layout(f);
+  float4 *tile = reinterpret_cast<float4 *>(smem + lay.tile);        // [n][nc]
+  uint32_t *uoff = reinterpret_cast<uint32_t *>(smem + lay.uoff);    // [5][umax][41]
+  float *syncbuf = reinterpret_cast<float *>(smem + lay.sync);       // [130][umax]
+  uint16_t *umap = reinterpret_cast<uint16_t *>(smem + lay.umap);    // [5][cell_hyps]
+
+  const int tid = threadIdx.x;
+  const int nwork = work[0];
+  // persistent workgroups: K2 compacted the (frame, candidate) pairs into a work
+  // list, so no workgroup is launched only to find it has no candidate
+  for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+  const int item = work[1 + wi];
+  const int b = item / f.cand_slots, j = item - b * f.cand_slots;
   uwspr_candidate *cand = cands + (size_t)b * f.maxfreqs + j;
   const float freq0 = cand->freq;
   // cc:341: if0 = freq/df + m (binary32), truncated
   const int if0 = (int)(ieee_divf(freq0, f.df) + (float)f.m);
+  const int r0 = if0 - 2 - f.ifr_lo;  // first of the 5 rows of the offset tables
 
-  // ---- stage the sqrt tile ------------------------------------------------
+  // ---- stage the sqrt tile and this candidate's offset rows ----------------
   const float *psb = ps + (size_t)b * f.n * f.band_w;
   const int c0 = if0 - 2 + f.off_min - f.band_lo;  // band column of centre index 0
   for (int idx = tid; idx < f.n * f.nc; idx += K3_THREADS) {
@@ -53,52 +81,90 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
     tile[idx] = make_float4(ieee_sqrtf(pr[-3]), ieee_sqrtf(pr[-1]), ieee_sqrtf(pr[1]),
                             ieee_sqrtf(pr[3]));
   }
+  const int nuw = UWSPR_NIFR * f.umax * 41;
+  for (int idx = tid; idx < nuw; idx += K3_THREADS) uoff[idx] = uoff_tab[(size_t)r0 * f.umax * 41 + idx];
+  for (int idx = tid; idx < UWSPR_NIFR * f.cell_hyps; idx += K3_THREADS)
+    umap[idx] = umap_tab[(size_t)r0 * f.cell_hyps + idx];
   __syncthreads();
 
-  // ---- one lane per hypothesis -------------------------------------------
-  const int hc = f.cell_hyps;
+  // ---- one lane per (cell, distinct offset sequence) -------------------------
   const int nc2 = 2 * f.nc;
-  for (int g = tid; g < f.ntot; g += K3_THREADS) {
-    const int cell = g / hc, h = g - cell * hc;
+  const int neval = UWSPR_NIFR * UWSPR_NK0 * f.umax;
+  for (int g = tid; g < neval; g += K3_THREADS) {
+    const int cell = g / f.umax, u = g - cell * f.umax;
     const int ifr_i = cell / UWSPR_NK0, k0 = cell - ifr_i * UWSPR_NK0;
-    const int ifr_idx = if0 - 2 + ifr_i - f.ifr_lo;
-    const uint32_t *ot = off_tab + (size_t)ifr_idx * 41 * hc + h;
+    const uint32_t *ot = uoff + (ifr_i * f.umax + u) * 41;
     int idx = k0 * f.nc + ifr_i - f.off_min;  // tile index of (row k0, offset 0)
     float ss = 0.0f, pw = 0.0f;
+    // Software pipeline: the 4 gathers of symbol group k4+1 (and the offset word
+    // of group k4+2) are in flight while group k4 is accumulated, so the LDS
+    // latency is paid once per 4 symbols instead of once per symbol.
+    float4 Pc[4], Pn[4];
+    uint32_t w1 = ot[0], w2 = ot[1];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) {
+      Pc[kk] = tile[idx + (int)(int8_t)(w1 >> (8 * kk))];
+      idx += nc2;  // kindex = k0 + 2k (cc:197)
+    }
 #pragma unroll
     for (int k4 = 0; k4 < 41; k4++) {
-      const uint32_t w = ot[(size_t)k4 * hc];
+      w1 = w2;
+      if (k4 + 2 < 41) w2 = ot[k4 + 2];
+      if (k4 + 1 < 41) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+          if (4 * (k4 + 1) + kk < UWSPR_NSYM) {
+            Pn[kk] = tile[idx + (int)(int8_t)(w1 >> (8 * kk))];
+            idx += nc2;
+          }
+        }
+      }
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
         const int k = 4 * k4 + kk;
         if (k < UWSPR_NSYM) {
-          const int o = (int)(int8_t)(w >> (8 * kk));
-          const float4 P = tile[idx + o];
-          idx += nc2;  // kindex = k0 + 2k (cc:197)
+          const float4 P = Pc[kk];
           const float cm = (P.y + P.w) - (P.x + P.z);
           ss = pr3_bit(k) ? ss + cm : ss - cm;  // (2*pr3[k]-1)*cm, cc:207
           pw = pw + P.x; pw = pw + P.y; pw = pw + P.z; pw = pw + P.w;  // cc:209
         }
       }
+#pragma unroll
+      for (int kk = 0; kk < 4; kk++) Pc[kk] = Pn[kk];
     }
     syncbuf[g] = ieee_divf(ss, pw);  // cc:357,390
   }
   __syncthreads();
 
+  const int hc = f.cell_hyps;
   if (syncgrid != nullptr && j < grid_cap) {
     float *gout = syncgrid + ((size_t)b * grid_cap + j) * f.ntot;
-    for (int g = tid; g < f.ntot; g += K3_THREADS) gout[g] = syncbuf[g];
+    for (int g = tid; g < f.ntot; g += K3_THREADS) {
+      const int cell = g / hc, h = g - cell * hc;
+      gout[g] = syncbuf[cell * f.umax + umap[(cell / UWSPR_NK0) * hc + h]];
+    }
   }
 
   // ---- replay the running-best selection in reference order ---------------
   if (tid < 64) {
     float best = -1e30f;
     int gbest = -1;
-    for (int base = 0; base < f.ntot; base += 64) {
-      const int g = base + tid;
-      const bool in = g < f.ntot;
-      const float v = in ? syncbuf[g] : 0.0f;
-      const bool lin = (g % hc) < f.nlin;
+    const int ncell = UWSPR_NIFR * UWSPR_NK0;
+    const int nper = (hc + 63) / 64;  // 64-lane slices per cell
+    // value of hypothesis h of a cell (expanded through the sequence map); the
+    // next slice is fetched while the current one is scanned
+    auto fetch = [&](int sl) -> float {
+      const int cell = sl / nper, h = (sl - cell * nper) * 64 + tid;
+      if (cell >= ncell || h >= hc) return 0.0f;
+      return syncbuf[cell * f.umax + umap[(cell / UWSPR_NK0) * hc + h]];
+    };
+    float vnext = fetch(0);
+    for (int sl = 0; sl < ncell * nper; sl++) {
+      const float v = vnext;
+      vnext = fetch(sl + 1);
+      const int cell = sl / nper, h = (sl - cell * nper) * 64 + tid;
+      const bool in = h < hc;
+      const bool lin = h < f.nlin;
       int start = 0;
       for (;;) {
         const bool pred = in && tid >= start &&
@@ -107,7 +173,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
         if (mask == 0ull) break;
         const int first = __ffsll((long long)mask) - 1;
         best = __shfl(v, first);
-        gbest = base + first;
+        gbest = cell * hc + (sl - cell * nper) * 64 + first;
         start = first + 1;
       }
     }
@@ -134,17 +200,19 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
       }
     }
   }
+  __syncthreads();  // LDS is reused by the next work item
+  }
 }
 
-size_t coarse_lds_bytes(const fdr_consts &f) {
-  return (size_t)f.n * f.nc * 16 + (size_t)f.ntot * 4;
-}
+size_t coarse_lds_bytes(const fdr_consts &f) { return k3_layout(f).total; }
 
 void launch_coarse(uwspr_ctx *c, int B) {
   const fdr_consts &f = c->fc;
   prof_scope ps(c, UWSPR_K_COARSE, (int64_t)B);
-  hipLaunchKernelGGL(k3_coarse, dim3(f.cand_slots, B), dim3(K3_THREADS), coarse_lds_bytes(f),
-                     c->stream, c->d_ps, f, c->d_off, c->d_cands, c->d_npk, c->d_syncgrid,
+  const long long items_max = (long long)f.cand_slots * B;
+  const int grid = (int)std::min<long long>(items_max, c->num_cus);
+  hipLaunchKernelGGL(k3_coarse, dim3(grid), dim3(K3_THREADS), coarse_lds_bytes(f), c->stream,
+                     c->d_ps, f, c->d_off, c->d_umap, c->d_cands, c->d_work, c->d_syncgrid,
                      c->d_syncgrid ? c->grid_cap : 0);
 }
 

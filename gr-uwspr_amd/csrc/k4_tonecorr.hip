@@ -6,25 +6,31 @@
 // lib/sync_and_demodulate_impl.cc:167-212 (per-symbol frequency cc:170-183,
 // phasor recurrence cc:186-199, correlation cc:200-211).
 //
-// Mapping: the (hypothesis, symbol) pairs are flattened, g = 162*h + i, and one
-// lane owns one pair: it derives its symbol frequency in binary64 exactly as
+// Mapping: the (hypothesis, symbol) pairs are flattened, g = 162*h + i.  A lane
+// owns one pair and T of its 4 tones (T = 1, 2 or 4; a wavefront covers 16*T
+// pairs).  The lane derives its symbol frequency in binary64 exactly as
 // cc:173/cc:179 do, takes cos/sin of the per-sample phase step in binary64
-// (cc:188-189), then walks the 256 samples in order, advancing the four tone
-// phasors by the reference's binary32 rotation recurrence (cc:193-195) and
-// accumulating inp/quad in the reference's operand order (cc:206-207).  Every
-// accumulator therefore sees the reference's exact sequence of binary32
-// operations (no FMA, no tree reduction) and p[] is bit-identical.
+// (cc:188-189), then walks the 256 samples in order, advancing its tone phasors
+// by the reference's binary32 rotation recurrence (cc:193-195) and accumulating
+// inp/quad in the reference's operand order (cc:206-207).  Every accumulator
+// sees the reference's exact sequence of binary32 operations (no FMA, no tree
+// reduction), so p[] is bit-identical.  T trades latency for overhead: T=1 gives
+// 4x the wavefronts and a 4x shorter serial chain (the 5..17-hypothesis stages of
+// the refinement schedule are latency-bound), T=4 amortises the sample reads
+// over all four tones (the 200-hypothesis sweep is throughput-bound).
 //
-// Samples reach the lanes through LDS: a wavefront's 64 symbol windows are 64
-// runs of 2 KB in HBM; per 16-sample chunk the wave loads them cooperatively
-// (16 lanes x 8 B = one 128-B run per window) into a per-wave LDS image whose
-// rows are padded to 136 B so the per-lane column reads (ds_read_b64, lane l at
-// row l) are bank-conflict free.  The next chunk's global loads are in flight
-// while the current chunk is computed.
+// Samples reach the lanes through LDS: a wavefront's symbol windows are runs of
+// 2 KB in HBM; per 16-sample chunk the wave loads them cooperatively (16 lanes x
+// 8 B = one 128-B run per window) into a per-wave LDS image whose rows are
+// padded to 136 B, so the per-lane column reads (ds_read_b64) are bank-conflict
+// free (lanes of one pair read the same address: broadcast).  The next chunk's
+// global loads are in flight while the current chunk is computed.
 //
 // Work per pair-sample: 32 correlation + 24 phasor binary32 ops = 56 VALU ops;
 // the kernel is FP32-VALU bound; HBM sees each frame about once
-// (L2 serves the re-reads by the other hypotheses of the frame).
+// (L2 / Infinity Cache serve the re-reads by the other hypotheses of the frame).
+#include <stdlib.h>
+
 #include "uwspr_internal.h"
 
 #pragma clang fp contract(off)
@@ -43,23 +49,27 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <int T>
 __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
     const float2 *__restrict__ frames, int fl, int nframes, const dev_hyp *__restrict__ hyps,
-    int H, float4 *__restrict__ p_out) {
-  __shared__ float lds_all[K4_WAVES][64 * K4_ROWDW];
+    int H, float *__restrict__ p_out) {
+  constexpr int PPW = 16 * T;        // pairs per wavefront
+  constexpr int LPP = 4 / T;         // lanes per pair
+  constexpr int NLD = PPW / 4;       // cooperative loads per lane per chunk
+  __shared__ float lds_all[K4_WAVES][PPW * K4_ROWDW];
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *lds = lds_all[wv];
 
   const long long total = (long long)H * UWSPR_NSYM;
-  const long long g0 = ((long long)blockIdx.x * K4_WAVES + wv) * 64;
+  const long long g0 = ((long long)blockIdx.x * K4_WAVES + wv) * PPW;
   if (g0 >= total) return;  // wave-uniform; no workgroup barrier is used below
 
-  // A wave's 64 pairs span at most two hypotheses (162 > 64).
+  // A wave's pairs span at most two hypotheses (162 > 64 >= PPW).
   const int hA = (int)(g0 / UWSPR_NSYM);
   const int iA0 = (int)(g0 - (long long)hA * UWSPR_NSYM);
-  const int sb = min(64, UWSPR_NSYM - iA0);  // lanes < sb belong to hA
+  const int sb = min(PPW, UWSPR_NSYM - iA0);  // pairs < sb belong to hA
   dev_hyp A = hyps[hA];
   dev_hyp Bh = hyps[min(hA + 1, H - 1)];
   const bool okA = A.frame >= 0 && A.frame < nframes;
@@ -68,15 +78,16 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
   if (!okA) { A.frame = 0; A.lag = 1 - 256 * iA0; }
   if (!okB) { Bh.frame = 0; Bh.lag = 1; }
 
-  const bool mineA = lane < sb;
-  const int own_i = mineA ? iA0 + lane : lane - sb;
-  const bool own_ok = mineA ? okA : (okB && (g0 + lane) < total);
+  const int pr = lane / LPP;           // this lane's pair within the wave
+  const int tone0 = (lane % LPP) * T;  // first of its T tones
+  const bool mineA = pr < sb;
+  const int own_i = mineA ? iA0 + pr : pr - sb;
+  const bool own_ok = mineA ? okA : (okB && (g0 + pr) < total);
   const int own_nb = (mineA ? A.lag : Bh.lag) + 256 * own_i;  // first sample index
   const bool interior = __all((own_nb > 0) && (own_nb + 255 < fl));
 
   // ---- per-symbol tone phasor steps (binary64 angle, cc:173-189) ----------
-  const float delta[4] = {-2.197265625f, -0.732421875f, 0.732421875f, 2.197265625f};
-  float cd[4], sd[4];
+  float cd[T], sd[T];
   {
     const dev_hyp &hy = mineA ? A : Bh;
     float fp;
@@ -87,8 +98,10 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
       fp = hy.f0 + hy.slmc;
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const double ang = kTwoPiDt * (double)(fp + delta[j]);
+    for (int j = 0; j < T; j++) {
+      // delta[] = {-1.5,-0.5,0.5,1.5} * (float)(375/256), cc:148 (exact in binary32)
+      const float delta = ((float)(tone0 + j) - 1.5f) * 1.46484375f;
+      const double ang = kTwoPiDt * (double)(fp + delta);
       double sn, cs;
       sincos(ang, &sn, &cs);
       cd[j] = (float)cs;
@@ -97,27 +110,27 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
   }
 
   // ---- cooperative loader geometry ---------------------------------------
-  // load t (0..15) of a chunk: window seg = 4t + lane/16, sample kk = lane%16
+  // load t (0..NLD-1) of a chunk: window seg = 4t + lane/16, sample kk = lane%16
   const int kk = lane & 15;
   const int segq = lane >> 4;
-  long long ebase[16];  // element index of sample 0 of that window (+kk), fast path
+  const float2 *src[NLD];  // sample 0 (+kk) of that window, fast path
 #pragma unroll
-  for (int t = 0; t < 16; t++) {
+  for (int t = 0; t < NLD; t++) {
     const int seg = 4 * t + segq;
     const bool sA = seg < sb;
     const int fr = sA ? A.frame : Bh.frame;
     const int nb = sA ? A.lag + 256 * (iA0 + seg) : Bh.lag + 256 * (seg - sb);
-    ebase[t] = (long long)fr * fl + nb + kk;
+    src[t] = frames + ((long long)fr * fl + nb + kk);
   }
 
-  float2 stage[16];
+  float2 stage[NLD];
   auto load_chunk = [&](int c) {
     if (interior) {
 #pragma unroll
-      for (int t = 0; t < 16; t++) stage[t] = frames[ebase[t] + 16 * c];
+      for (int t = 0; t < NLD; t++) stage[t] = src[t][16 * c];
     } else {
 #pragma unroll
-      for (int t = 0; t < 16; t++) {
+      for (int t = 0; t < NLD; t++) {
         const int seg = 4 * t + segq;
         const bool sA = seg < sb;
         const long long fb = (long long)(sA ? A.frame : Bh.frame) * fl;
@@ -130,22 +143,23 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
     }
   };
 
-  float c[4] = {1.0f, 1.0f, 1.0f, 1.0f}, s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  float inp[4] = {0.0f, 0.0f, 0.0f, 0.0f}, quad[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float c[T], s[T], inp[T], quad[T];
+#pragma unroll
+  for (int j = 0; j < T; j++) { c[j] = 1.0f; s[j] = 0.0f; inp[j] = 0.0f; quad[j] = 0.0f; }
 
   load_chunk(0);
   for (int ch = 0; ch < 16; ch++) {
     wave_lds_fence();  // previous chunk's reads are done before rows are rewritten
 #pragma unroll
-    for (int t = 0; t < 16; t++)
+    for (int t = 0; t < NLD; t++)
       *reinterpret_cast<float2 *>(&lds[(4 * t + segq) * K4_ROWDW + 2 * kk]) = stage[t];
     wave_lds_fence();
     if (ch < 15) load_chunk(ch + 1);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const float2 x = *reinterpret_cast<const float2 *>(&lds[lane * K4_ROWDW + 2 * k]);
+      const float2 x = *reinterpret_cast<const float2 *>(&lds[pr * K4_ROWDW + 2 * k]);
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
+      for (int j = 0; j < T; j++) {
         // cc:206-207, left to right
         inp[j] = (inp[j] + x.x * c[j]) + x.y * s[j];
         quad[j] = (quad[j] - x.x * s[j]) + x.y * c[j];
@@ -157,15 +171,27 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
     }
   }
 
-  if (g0 + lane < total) {
-    float4 p;
-    p.x = ieee_sqrtf(inp[0] * inp[0] + quad[0] * quad[0]);  // cc:211
-    p.y = ieee_sqrtf(inp[1] * inp[1] + quad[1] * quad[1]);
-    p.z = ieee_sqrtf(inp[2] * inp[2] + quad[2] * quad[2]);
-    p.w = ieee_sqrtf(inp[3] * inp[3] + quad[3] * quad[3]);
-    if (!own_ok) p = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    p_out[g0 + lane] = p;
+  if (g0 + pr < total) {
+    float *out = p_out + (g0 + pr) * 4 + tone0;  // p[pair][tone]
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+      const float pj = ieee_sqrtf(inp[j] * inp[j] + quad[j] * quad[j]);  // cc:211
+      out[j] = own_ok ? pj : 0.0f;
+    }
   }
+}
+
+static int k4_choose_t(long long pairs) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char *e = getenv("UWSPR_K4_T");
+    forced = e ? atoi(e) : 0;
+  }
+  if (forced == 1 || forced == 2 || forced == 4) return forced;
+  // enough wavefronts to fill 256 CUs x 4 SIMDs several times over -> amortise
+  if (pairs >= 4LL * 1024 * 1024) return 4;
+  if (pairs >= 1024 * 1024) return 2;
+  return 1;
 }
 
 void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int H,
@@ -173,10 +199,15 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
   if (H <= 0) return;
   prof_scope ps(c, UWSPR_K_TONECORR, H);
   const long long total = (long long)H * UWSPR_NSYM;
-  const long long waves = (total + 63) / 64;
+  const int T = k4_choose_t(total);
+  const long long waves = (total + 16 * T - 1) / (16 * T);
   const unsigned blocks = (unsigned)((waves + K4_WAVES - 1) / K4_WAVES);
-  hipLaunchKernelGGL(k4_tonecorr, dim3(blocks), dim3(64 * K4_WAVES), 0, c->stream,
-                     (const float2 *)frames, c->fc.fl, B, hyps, H, p);
+  const float2 *fr = (const float2 *)frames;
+  float *po = (float *)p;
+  dim3 blk(64 * K4_WAVES);
+  if (T == 1) hipLaunchKernelGGL(k4_tonecorr<1>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, hyps, H, po);
+  else if (T == 2) hipLaunchKernelGGL(k4_tonecorr<2>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, hyps, H, po);
+  else hipLaunchKernelGGL(k4_tonecorr<4>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, hyps, H, po);
 }
 
 }  // namespace uwspr

@@ -64,12 +64,102 @@ __global__ __launch_bounds__(256) void k5_fold(const dev_hyp *__restrict__ hyps,
   }
 }
 
+// Wave-per-hypothesis form of the same fold, for launches too small to fill the
+// chip with one lane per hypothesis (the schedule stages: 5..17 hypotheses per
+// candidate).  All loads/stores are coalesced; the per-symbol terms are formed
+// by 162 lanes in parallel and only the order-sensitive running sums are
+// serial: lane 0 adds the 648 magnitudes (cc:213), lane 1 the 162 signed
+// metrics (cc:215), lanes 2/3 the binary64-stepped fsum / f2sum (cc:243-244).
+constexpr int K5W_WAVES = 4;
+__device__ __forceinline__ void k5_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave(
+    const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p, int H, float symfac,
+    float *__restrict__ sync, uint8_t *__restrict__ symbols) {
+  __shared__ float4 str_all[K5W_WAVES][2][UWSPR_NSYM];   // [0]: magnitudes, [1]: (0,0,0,+-cmet)
+  __shared__ double q_all[K5W_WAVES][2][UWSPR_NSYM];     // fs/162, fs*fs/162
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = blockIdx.x * K5W_WAVES + wv;
+  if (h >= H) return;  // wave-uniform
+  const bool soft = symbols != nullptr;
+  if (hyps[h].frame < 0) {
+    if (lane == 0) sync[h] = -1e30f;
+    if (soft)
+      for (int i = lane; i < UWSPR_NSYM; i += 64) symbols[(size_t)h * UWSPR_NSYM + i] = 0;
+    return;
+  }
+  float4 *pf = str_all[wv][0];
+  float4 *sc = str_all[wv][1];
+  double *q1 = q_all[wv][0], *q2 = q_all[wv][1];
+  float fs[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int i = lane + 64 * r;
+    fs[r] = 0.0f;
+    if (i < UWSPR_NSYM) {
+      const float4 P = p[(size_t)h * UWSPR_NSYM + i];
+      const bool bit = pr3_rt(i);
+      pf[i] = P;
+      const float cmet = (P.y + P.w) - (P.x + P.z);   // cc:214
+      // ss -/+ cmet == ss + (-/+cmet); the three +0 terms leave ss unchanged
+      sc[i] = make_float4(0.0f, 0.0f, 0.0f, bit ? cmet : -cmet);
+      fs[r] = bit ? P.w - P.y : P.z - P.x;            // cc:219,222
+      if (soft) {
+        q1[i] = (double)fs[r] / 162.0;                // cc:243
+        q2[i] = (double)(fs[r] * fs[r]) / 162.0;      // cc:244
+      }
+    }
+  }
+  k5_wave_fence();
+  float acc = 0.0f;
+  if (lane < 2) {
+    // lane 0: totp = (((totp+p0)+p1)+p2)+p3 per symbol (cc:213); lane 1: ss (cc:215)
+    const float4 *st = str_all[wv][lane];
+#pragma unroll 9
+    for (int i = 0; i < UWSPR_NSYM; i++) {
+      const float4 P = st[i];
+      acc = acc + P.x; acc = acc + P.y; acc = acc + P.z; acc = acc + P.w;
+    }
+  } else if (soft && lane < 4) {
+    const double *q = q_all[wv][lane - 2];
+#pragma unroll 9
+    for (int i = 0; i < UWSPR_NSYM; i++) acc = (float)((double)acc + q[i]);
+  }
+  const float totp = __shfl(acc, 0), ss = __shfl(acc, 1);
+  if (lane == 0) sync[h] = ieee_divf(ss, totp);  // cc:226
+  if (soft) {
+    const float fsum = __shfl(acc, 2), f2sum = __shfl(acc, 3);
+    const float fac = ieee_sqrtf(f2sum - fsum * fsum);  // cc:246
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const int i = lane + 64 * r;
+      if (i < UWSPR_NSYM) {
+        float v = ieee_divf(symfac * fs[r], fac);  // cc:248
+        if (v > 127.0f) v = 127.0f;
+        if (v < -128.0f) v = -128.0f;
+        v = v + 128.0f;
+        symbols[(size_t)h * UWSPR_NSYM + i] = (v != v) ? (uint8_t)0 : (uint8_t)(int)v;
+      }
+    }
+  }
+}
+
 void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, float *sync,
                  uint8_t *symbols) {
   if (H <= 0) return;
   prof_scope ps(c, UWSPR_K_FOLD, H);
-  hipLaunchKernelGGL(k5_fold, dim3((H + 255) / 256), dim3(256), 0, c->stream, hyps, p, H, 50.0f,
-                     sync, symbols);
+  if (H <= 65536) {
+    hipLaunchKernelGGL(k5_fold_wave, dim3((H + K5W_WAVES - 1) / K5W_WAVES), dim3(64 * K5W_WAVES), 0,
+                       c->stream, hyps, p, H, 50.0f, sync, symbols);
+  } else {
+    hipLaunchKernelGGL(k5_fold, dim3((H + 255) / 256), dim3(256), 0, c->stream, hyps, p, H, 50.0f,
+                       sync, symbols);
+  }
 }
 
 // ----------------------------------------------------- ABI hyp -> device hyp

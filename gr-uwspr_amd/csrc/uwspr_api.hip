@@ -90,10 +90,10 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->p = *p;
   c->device = device;
   c->own_stream = c->stream = nullptr;
-  c->d_window = c->d_twiddle = nullptr; c->d_off = nullptr;
+  c->d_window = c->d_twiddle = nullptr; c->d_off = nullptr; c->d_umap = nullptr;
   c->cap_frames_bytes = 0; c->d_frames = nullptr; c->cap_B = 0;
   c->d_ps = c->d_psavg = c->d_smraw = c->d_smspec = c->d_noise = nullptr;
-  c->d_cands = nullptr; c->d_npk = nullptr; c->last_B = 0;
+  c->d_cands = nullptr; c->d_npk = nullptr; c->d_work = nullptr; c->last_B = 0; c->num_cus = 256;
   c->grid_cap = 0; c->cap_grid_bytes = 0; c->d_syncgrid = nullptr;
   c->cap_hyps = 0; c->d_hyps = nullptr; c->cap_abi_hyps = 0; c->d_abi_hyps = nullptr;
   c->cap_p = 0; c->d_p = nullptr; c->cap_sync = 0; c->d_sync = nullptr;
@@ -173,9 +173,6 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
                 "(the reference reads out of bounds here)", p->halfbandwidth, lo, hi, size - 1);
   f.band_lo = lo; f.band_w = hi - lo + 1;
   f.cand_slots = std::min(p->maxfreqs, std::max(1, (f.finpb - 1) / 2));
-  if (coarse_lds_bytes(f) > 160 * 1024)
-    return fail(c, UWSPR_ERR_UNSUPPORTED, "coarse search needs %zu B of LDS (> 160 KiB): reduce maxdrift/cf",
-                coarse_lds_bytes(f));
 
   // ---- device -------------------------------------------------------------
   int ndev = 0;
@@ -186,6 +183,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   hipDeviceProp_t prop;
   HIPCHK(c, hipGetDeviceProperties(&prop, device));
   snprintf(c->device_name, sizeof(c->device_name), "%s", prop.gcnArchName);
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(c, UWSPR_ERR_NODEVICE, "device %d is %s; kernels are built for gfx950 only", device,
                 prop.gcnArchName);
@@ -201,16 +199,38 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
     tw[2 * k + 1] = (float)(-sin(ang));
   }
   tw[0] = 1.0f; tw[1] = 0.0f; tw[256] = 0.0f; tw[257] = -1.0f;
-  // pack offsets 4 symbols per word, [ifr][k4][h]
-  std::vector<uint32_t> offw((size_t)f.n_ifr * 41 * f.cell_hyps);
+  // distinct offset sequences per ifr row (identical sequences give identical metrics)
+  std::vector<std::vector<int>> uniq_of(f.n_ifr);           // first hypothesis of each distinct sequence
+  std::vector<uint16_t> umap((size_t)f.n_ifr * f.cell_hyps);
+  f.umax = 0;
+  for (int r = 0; r < f.n_ifr; r++) {
+    for (int h = 0; h < f.cell_hyps; h++) {
+      const int8_t *sh = &off[((size_t)r * f.cell_hyps + h) * 164];
+      int u = -1;
+      for (size_t q = 0; q < uniq_of[r].size(); q++)
+        if (memcmp(sh, &off[((size_t)r * f.cell_hyps + uniq_of[r][q]) * 164], UWSPR_NSYM) == 0) { u = (int)q; break; }
+      if (u < 0) { u = (int)uniq_of[r].size(); uniq_of[r].push_back(h); }
+      umap[(size_t)r * f.cell_hyps + h] = (uint16_t)u;
+    }
+    f.umax = std::max(f.umax, (int)uniq_of[r].size());
+  }
+  // [ifr][u][k4] words of 4 x int8; rows with fewer distinct sequences repeat sequence 0
+  std::vector<uint32_t> offw((size_t)f.n_ifr * f.umax * 41);
   for (int r = 0; r < f.n_ifr; r++)
-    for (int k4 = 0; k4 < 41; k4++)
-      for (int h = 0; h < f.cell_hyps; h++) {
+    for (int u = 0; u < f.umax; u++) {
+      const int h = u < (int)uniq_of[r].size() ? uniq_of[r][u] : uniq_of[r][0];
+      for (int k4 = 0; k4 < 41; k4++) {
         uint32_t v = 0;
         for (int kk = 0; kk < 4; kk++)
           v |= (uint32_t)(uint8_t)off[((size_t)r * f.cell_hyps + h) * 164 + 4 * k4 + kk] << (8 * kk);
-        offw[((size_t)r * 41 + k4) * f.cell_hyps + h] = v;
+        offw[((size_t)r * f.umax + u) * 41 + k4] = v;
       }
+    }
+  if (coarse_lds_bytes(f) > 160 * 1024)
+    return fail(c, UWSPR_ERR_UNSUPPORTED, "coarse search needs %zu B of LDS (> 160 KiB): reduce maxdrift/cf",
+                coarse_lds_bytes(f));
+  HIPCHK(c, hipMalloc((void **)&c->d_umap, umap.size() * sizeof(uint16_t)));
+  HIPCHK(c, hipMemcpy(c->d_umap, umap.data(), umap.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   HIPCHK(c, hipMalloc((void **)&c->d_window, size * sizeof(float)));
   HIPCHK(c, hipMalloc((void **)&c->d_twiddle, size * sizeof(float)));
   HIPCHK(c, hipMalloc((void **)&c->d_off, offw.size() * sizeof(uint32_t)));
@@ -224,8 +244,8 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
 extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   if (!c) return;
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
-  void *bufs[] = {c->d_window, c->d_twiddle, c->d_off, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
-                  c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_syncgrid, c->d_hyps,
+  void *bufs[] = {c->d_window, c->d_twiddle, c->d_off, c->d_umap, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
+                  c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps,
                   c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout};
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (auto &e : c->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -321,6 +341,7 @@ static int ensure_fdr(uwspr_ctx *c, int B) {
   GROW(c->d_noise, (size_t)B);
   GROW(c->d_cands, (size_t)B * f.maxfreqs);
   GROW(c->d_npk, (size_t)B);
+  GROW(c->d_work, (size_t)B * f.cand_slots + 1);
 #undef GROW
   c->cap_B = B;
   return UWSPR_OK;

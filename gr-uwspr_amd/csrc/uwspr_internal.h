@@ -53,6 +53,7 @@ struct fdr_consts {
   int cell_hyps, nlin, ntot;      // hyps per (ifr,k0) cell; linear ones; 130*cell_hyps
   int off_min, off_max, nc;       // ifd-ifr range; tile centres per row = 5 + off_max-off_min
   int ifr_lo, n_ifr;              // rows of the offset table
+  int umax;                       // distinct offset sequences per cell (max over rows)
   int cand_slots;                 // max candidates a frame can yield
   float df, min_snr, min_snr_floor, threshold;
 };
@@ -65,6 +66,7 @@ struct uwspr_ctx {
   uwspr_params p;
   uwspr::fdr_consts fc;
   int device;
+  int num_cus;
   char device_name[64];
   hipStream_t own_stream, stream;
   char err[512];
@@ -72,7 +74,8 @@ struct uwspr_ctx {
   // constant tables in HBM
   float *d_window;     // [512]
   float *d_twiddle;    // [256][2]
-  uint32_t *d_off;     // [n_ifr][41][cell_hyps], 4 x int8 (ifd-ifr) per word
+  uint32_t *d_off;     // [n_ifr][umax][41]: distinct offset sequences, 4 x int8 (ifd-ifr) per word
+  uint16_t *d_umap;    // [n_ifr][cell_hyps]: hypothesis -> distinct sequence
 
   // batch scratch (grown on demand, never shrunk)
   size_t cap_frames_bytes; float *d_frames;       // staging when frames are host memory
@@ -84,6 +87,7 @@ struct uwspr_ctx {
   float *d_noise;       // [B]
   uwspr_candidate *d_cands;  // [B][maxfreqs]
   int32_t *d_npk;       // [B]
+  int32_t *d_work;      // [1 + B*cand_slots]: count, then frame*cand_slots + j items
   int last_B;
   int grid_cap; size_t cap_grid_bytes; float *d_syncgrid;  // [B][grid_cap][ntot]
 
