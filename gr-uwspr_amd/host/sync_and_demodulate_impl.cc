@@ -1,0 +1,102 @@
+// sync_and_demodulate_impl.cc -- host block mirror of
+// gr::uwspr::sync_and_demodulate (lib/sync_and_demodulate_impl.cc:315-534):
+// candidates PDU in, one 7-byte blob PDU out per decoded candidate, in candidate
+// order.  The refinement schedule S0..S5 runs on the GPU for all candidates of
+// the frame in one uwspr_demod_batch call; the gate/retry/Fano loop (cc:457-490)
+// is replayed on the host by uwspr_decode_candidate.
+#include <stdio.h>
+#include <time.h>
+
+#include <stdexcept>
+#include <string>
+
+#include "uwspr/sync_and_demodulate.h"
+
+namespace gr {
+namespace uwspr {
+
+class sync_and_demodulate_impl : public sync_and_demodulate {
+ public:
+  sync_and_demodulate_impl(int fs, int fl, int spb, int maxdrift, int maxfreqs, int cf)
+      : block("sync_and_demodulate"), d_ctx(nullptr), d_fl(fl), d_framecount(0), d_log(nullptr) {
+    // lib/sync_and_demodulate_impl.cc:69-75
+    message_port_register_in("in");
+    set_msg_handler("in", [this](message_sptr m) { demodulate(std::move(m)); });
+    message_port_register_out("out");
+    // fs/fl/spb/maxdrift are stored but unused by the reference's math (cc:77-93);
+    // the FDR-only parameters take the flowgraph values.
+    uwspr_params p = {fs, fl, spb, maxdrift, maxfreqs, 10, cf, 10};
+    int rc = uwspr_ctx_create(&p, 0, &d_ctx);
+    if (rc != UWSPR_OK) {
+      std::string msg = d_ctx ? uwspr_last_error(d_ctx) : uwspr_status_string(rc);
+      if (d_ctx) uwspr_ctx_destroy(d_ctx);
+      d_ctx = nullptr;
+      throw std::runtime_error("uwspr.sync_and_demodulate: " + msg);
+    }
+    time(&d_start);
+  }
+  ~sync_and_demodulate_impl() override {
+    if (d_ctx) uwspr_ctx_destroy(d_ctx);
+    if (d_log) fclose(d_log);
+  }
+  void set_messagelog(bool on) override {
+    if (on && !d_log) {
+      d_log = fopen("messagelog.txt", "a");  // cc:98-108
+      if (d_log) { fprintf(d_log, "Start time: %s\n", asctime(localtime(&d_start))); fflush(d_log); }
+    } else if (!on && d_log) {
+      fclose(d_log);
+      d_log = nullptr;
+    }
+  }
+  unsigned framecount() const override { return d_framecount; }
+
+ private:
+  void demodulate(message_sptr msg) {
+    auto in = std::dynamic_pointer_cast<const candidates_pdu>(msg);
+    if (!in || !in->samples || (int)in->samples->samples.size() != d_fl) return;
+    const int npk = in->npk;
+    if (npk <= 0) return;
+    std::vector<float> frame((size_t)d_fl * 2);
+    for (int i = 0; i < d_fl; i++) {
+      frame[2 * (size_t)i] = in->samples->samples[i].real();      // cc:344-345
+      frame[2 * (size_t)i + 1] = in->samples->samples[i].imag();
+    }
+    std::vector<uwspr_demod_out> out(npk);
+    int32_t n = npk;
+    int rc = uwspr_demod_batch(d_ctx, frame.data(), 1, UWSPR_HOST, in->candidates.data(), &n, npk,
+                               npk, out.data());
+    if (rc != UWSPR_OK)
+      throw std::runtime_error(std::string("uwspr.sync_and_demodulate: ") + uwspr_last_error(d_ctx));
+    for (int j = 0; j < npk; j++) {  // cc:389
+      int8_t m7[7];
+      int32_t idt = -1;
+      if (!uwspr_decode_candidate(&out[j], m7, &idt)) continue;
+      d_framecount++;  // cc:492
+      if (d_log) {
+        const candidate_t &c = in->candidates[j];
+        fprintf(d_log, "Frame: %u\nBaseband freq is %2.2f Hz\n(6 Hz) SNR is %2.2f dB\nData: ",
+                d_framecount, c.freq, c.snr);
+        for (int i = 0; i < 7; i++) fprintf(d_log, "%02x", (unsigned)(unsigned char)m7[i]);
+        fprintf(d_log, "\n\n");
+        fflush(d_log);
+      }
+      auto blob = std::make_shared<blob_pdu>();
+      for (int i = 0; i < 7; i++) blob->bytes[i] = m7[i];
+      message_port_pub("out", blob);  // cc:528-530
+    }
+  }
+
+  uwspr_ctx *d_ctx;
+  int d_fl;
+  unsigned d_framecount;
+  FILE *d_log;
+  time_t d_start;
+};
+
+sync_and_demodulate::sptr sync_and_demodulate::make(int fs, int fl, int spb, int maxdrift,
+                                                    int maxfreqs, int cf) {
+  return sptr(new sync_and_demodulate_impl(fs, fl, spb, maxdrift, maxfreqs, cf));
+}
+
+}  // namespace uwspr
+}  // namespace gr

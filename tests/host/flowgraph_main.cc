@@ -1,0 +1,86 @@
+// flowgraph_main.cc -- drives the host block mirror the way the reference's
+// receive flowgraph does (examples/WaveFilePlusNoiseDecode.grc, the part after
+// the resampler):  stream -> sliding_window_stream_to_pdu(375,45000,9,2)
+//   -> FDR(375,45000,256,0,200,10,1500,10) -> sync_and_demodulate(375,45000,256,0,200,1500)
+//   -> WSPR_unpacker() -> sink
+// modes:  framer | errors | decode <file.c2>
+#include <stdio.h>
+#include <string.h>
+
+#include <stdexcept>
+#include <vector>
+
+#include "uwspr/FDR.h"
+#include "uwspr/WSPR_unpacker.h"
+#include "uwspr/sliding_window_stream_to_pdu.h"
+#include "uwspr/sync_and_demodulate.h"
+
+using namespace gr::uwspr;
+
+static int framer() {
+  auto sw = sliding_window_stream_to_pdu::make(375, 45000, 9, 2);
+  message_sink sink;
+  block::msg_connect(sw.get(), "out", &sink, "in");
+  std::vector<gr_complex> ramp(4096);
+  long n = 0;
+  for (int call = 0; call < 30; call++) {  // 122880 samples
+    for (auto &v : ramp) { v = gr_complex((float)n, -(float)n); n++; }
+    if (sw->work((int)ramp.size(), ramp.data()) != (int)ramp.size()) return 2;
+  }
+  printf("pdus %zu\n", sink.received.size());
+  for (auto &m : sink.received) {
+    auto p = std::dynamic_pointer_cast<const samples_pdu>(m);
+    printf("first %.0f last %.0f size %zu\n", p->samples.front().real(), p->samples.back().real(),
+           p->samples.size());
+  }
+  return 0;
+}
+
+static int errors() {
+  int seen = 0;
+  try { FDR::make(375, 45000, 256, 0, 200, 200, 1500, 10); } catch (const std::invalid_argument &e) {
+    printf("invalid_argument: %s\n", e.what()); seen |= 1; }
+  try { FDR::make(375, 45000, 256, 0, 200, 187, 1500, 10); } catch (const std::invalid_argument &e) {
+    printf("invalid_argument: %s\n", e.what()); seen |= 2; }
+  try { auto f = FDR::make(375, 45000, 256, 0, 200, 10, 1500, 10); printf("FDR created on a GPU\n"); seen |= 4; }
+  catch (const std::runtime_error &e) { printf("runtime_error: %s\n", e.what()); seen |= 8; }
+  printf("seen %d\n", seen);
+  return ((seen & 3) == 3 && (seen & 12)) ? 0 : 1;
+}
+
+static int decode(const char *path) {
+  std::vector<float> iq(2 * 45000);
+  if (uwspr_c2_read(path, iq.data(), nullptr, nullptr) != 0) { printf("cannot read %s\n", path); return 2; }
+  auto sw = sliding_window_stream_to_pdu::make(375, 45000, 9, 2);
+  auto fdr = FDR::make(375, 45000, 256, 0, 200, 10, 1500, 10);
+  auto sad = sync_and_demodulate::make(375, 45000, 256, 0, 200, 1500);
+  auto unp = WSPR_unpacker::make();
+  message_sink cands, texts;
+  block::msg_connect(sw.get(), "out", fdr.get(), "in");
+  block::msg_connect(fdr.get(), "out", sad.get(), "in");
+  block::msg_connect(fdr.get(), "out", &cands, "in");
+  block::msg_connect(sad.get(), "out", unp.get(), "in");
+  block::msg_connect(unp.get(), "out", &texts, "in");
+  std::vector<gr_complex> s(45000);
+  for (int i = 0; i < 45000; i++) s[i] = gr_complex(iq[2 * i], iq[2 * i + 1]);
+  for (int off = 0; off < 45000; off += 4500) sw->work(4500, s.data() + off);
+  printf("ports %d%d%d%d\n", fdr->has_in("in"), fdr->has_out("out"), sad->has_in("in"), sad->has_out("out"));
+  for (auto &m : cands.received) {
+    auto c = std::dynamic_pointer_cast<const candidates_pdu>(m);
+    printf("npk %d\n", c->npk);
+    for (auto &k : c->candidates)
+      printf("cand type %d freq %.9f sync %.9f shift %d V1 %.1f V2 %.1f p1 %d p2 %d\n", k.m_type, k.freq,
+             k.sync, k.shift, k.m_nonlinear.V1, k.m_nonlinear.V2, k.m_nonlinear.p1, k.m_nonlinear.p2);
+  }
+  for (auto &m : texts.received) printf("text %s\n", std::dynamic_pointer_cast<const text_pdu>(m)->text.c_str());
+  printf("frames %u\n", sad->framecount());
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc >= 2 && !strcmp(argv[1], "framer")) return framer();
+  if (argc >= 2 && !strcmp(argv[1], "errors")) return errors();
+  if (argc >= 3 && !strcmp(argv[1], "decode")) return decode(argv[2]);
+  fprintf(stderr, "usage: %s framer | errors | decode file.c2\n", argv[0]);
+  return 64;
+}

@@ -1,0 +1,90 @@
+"""N>1 path on CPU: world_size-2 gloo processes exercise the round-robin frame
+sharding, the fixed-size slab packing and the gather-to-rank-0 + order restore
+that bench.py uses over RCCL on GPUs (gr-uwspr_amd/dist.py).  No data-path
+collective exists: frames are independent."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    import gr_uwspr_amd as G
+    from gr_uwspr_amd import dist as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N = G.native
+    mine = D.shard_indices(total, rank, world)
+    bl = (total + world - 1) // world             # equal-sized shards (padded)
+    maxfreqs, per = 4, 1
+    cands = np.zeros((bl, maxfreqs), N.CAND_DTYPE)
+    npk = np.zeros(bl, np.int32)
+    demod = np.zeros((bl, per), N.DEMOD_DTYPE)
+    for li, b in enumerate(mine):                 # fabricate results that encode the global index
+        npk[li] = 1 + b % 3
+        cands[li, :npk[li]]["freq"] = b + 0.25
+        cands[li, :npk[li]]["shift"] = 128 * (b % 26)
+        demod[li, 0]["f1"] = b + 0.5
+        demod[li, 0]["shift1"] = 1000 + b
+    slab = D.pack_slabs(torch.from_numpy(np.frombuffer(cands.tobytes(), np.uint8).copy()),
+                        torch.from_numpy(npk), torch.from_numpy(np.frombuffer(demod.tobytes(), np.uint8).copy()),
+                        maxfreqs, per, N.DEMOD_DTYPE.itemsize)
+    g = D.gather_slabs(slab, dst=0)
+    if rank == 0:
+        allf = D.restore_order(g, total).numpy()
+        ok = allf.shape == (total, D.SLAB_BYTES)
+        for b in range(total):
+            n, cs, f1, sh, dr, sy = D.unpack_slab(allf[b], N.CAND_DTYPE)
+            ok &= n == 1 + b % 3 and len(cs) == n and float(cs[0]["freq"]) == b + 0.25
+            ok &= int(cs[0]["shift"]) == 128 * (b % 26) and f1 == b + 0.5 and sh == 1000 + b
+        q.put(bool(ok))
+    else:
+        assert g is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [10, 7])
+def test_gloo_world2_shard_gather_restore(total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
+def test_shard_indices_cover_everything_once():
+    from gr_uwspr_amd import dist as D
+    for total in (1, 8, 65536 // 64 + 3):
+        for world in (1, 2, 4, 8):
+            allb = np.concatenate([D.shard_indices(total, r, world) for r in range(world)])
+            assert sorted(allb.tolist()) == list(range(total))
+            assert sum(D.local_count(total, r, world) for r in range(world)) == total
+
+
+def test_gather_is_identity_without_a_process_group():
+    from gr_uwspr_amd import dist as D
+    x = torch.arange(12, dtype=torch.uint8).reshape(3, 4)
+    assert torch.equal(D.gather_slabs(x)[0], x)

@@ -1,0 +1,71 @@
+"""Host block mirror (gr-uwspr_amd/host): same class names, make() signatures,
+port names and PDU schemas as include/uwspr/*.h of the reference, on top of the
+C ABI.  The C++ driver tests/host/flowgraph_main.cc wires the receive flowgraph."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+EXE = os.path.join(ROOT, "tests", "host", "_flowgraph")
+
+
+@pytest.fixture(scope="module")
+def exe(G):
+    G.native.build()
+    libdir = G.native.LIBDIR
+    src = os.path.join(ROOT, "tests", "host", "flowgraph_main.cc")
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src),
+                                                              os.path.getmtime(G.native.HOSTLIB)):
+        subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "gr-uwspr_amd", "host"),
+                        "-I" + os.path.join(ROOT, "include"), src, "-o", EXE, "-L" + libdir,
+                        "-luwspr_blocks", "-luwspr_hip", "-Wl,-rpath," + libdir], check=True)
+    return EXE
+
+
+def test_public_headers_keep_the_reference_signatures():
+    h = os.path.join(ROOT, "gr-uwspr_amd", "host", "uwspr")
+    fdr = open(os.path.join(h, "FDR.h")).read()
+    assert "static sptr make(int fs, int fl, int spb, int maxdrift, int maxfreqs, int halfbandwidth, int cf," in fdr
+    sad = open(os.path.join(h, "sync_and_demodulate.h")).read()
+    assert "static sptr make(int fs, int fl, int spb, int maxdrift, int maxfreqs, int cf);" in sad
+    sw = open(os.path.join(h, "sliding_window_stream_to_pdu.h")).read()
+    assert "static sptr make(int fs, int fl, int shift, int C);" in sw
+
+
+def test_sliding_window_framing(exe):
+    """sliding_window_stream_to_pdu_impl.cc:97-138: one PDU per work() call once
+    fl samples are buffered; hop = shift*fs = 3375; overlap fl - 3375."""
+    out = subprocess.run([exe, "framer"], capture_output=True, text=True, check=True).stdout.split("\n")
+    # python restatement of the same rule on the same 30 x 4096-sample calls
+    count, start, exp = 0, 0, []
+    for _ in range(30):
+        count += 4096
+        if count >= 45000:
+            exp.append((start, start + 44999))
+            start += 3375
+            count -= 3375
+    assert out[0] == "pdus %d" % len(exp) and len(exp) > 5
+    for line, (a, b) in zip(out[1:], exp):
+        assert line == "first %d last %d size 45000" % (a, b)
+
+
+def test_error_behaviour(exe):
+    r = subprocess.run([exe, "errors"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Half pass bandwidth (200) must be lower than max freq range (187)" in r.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert "no CPU fallback" in r.stdout   # loud failure, not a silent fallback
+
+
+@pytest.mark.gpu
+def test_receive_flowgraph_decodes_ve3emb(exe):
+    r = subprocess.run([exe, "decode", os.path.join(GOLDEN, "VE3EMB.c2")], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ports 1111" in r.stdout and "npk 1" in r.stdout
+    assert "cand type 1 freq -0.732421875 sync 0.596573055 shift 256 V1 -1.0 V2 -1.0 p1 0 p2 650" in r.stdout
+    assert "text VE3EMB FN25 30" in r.stdout and "frames 1" in r.stdout
