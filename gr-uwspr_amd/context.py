@@ -204,6 +204,14 @@ class Context:
                                               C.c_void_p(npk_t.data_ptr()),
                                               C.c_void_p(out_t.data_ptr())))
 
+    def pack_slabs_into(self, B, K, slab_t):
+        """Per-frame gather slabs of the last pipeline batch, written into a torch
+        CUDA uint8 tensor [B, 32+48K] (or a numpy array for the host form)."""
+        if _is_torch(slab_t):
+            self._chk(self.L.uwspr_pack_slabs(self.h, B, K, C.c_void_p(slab_t.data_ptr()), N.DEVICE))
+        else:
+            self._chk(self.L.uwspr_pack_slabs(self.h, B, K, C.c_void_p(slab_t.ctypes.data), N.HOST))
+
     def sync_sweep_into(self, frames, hyps_t, H, sync_t, sym_t):
         p, B, where, keep = self._frames(frames)
         assert where == N.DEVICE
@@ -212,8 +220,16 @@ class Context:
                                           C.c_void_p(sym_t.data_ptr()) if sym_t is not None else None))
 
     # -- measurement -------------------------------------------------------
-    def prof_enable(self, on=True):
-        self._chk(self.L.uwspr_prof_enable(self.h, 1 if on else 0))
+    def prof_enable(self, which=True):
+        """which: True = every kernel family, False/0 = off, or an iterable of
+        family names from native.K_NAMES (e.g. ("tonecorr",))."""
+        if which is True:
+            mask = 0x3F
+        elif not which:
+            mask = 0
+        else:
+            mask = sum(1 << N.K_NAMES.index(k) for k in which)
+        self._chk(self.L.uwspr_prof_enable(self.h, mask))
 
     def prof_read(self):
         p = N.Prof()

@@ -24,7 +24,8 @@ constexpr int K1_ROWS_PER_WAVE = 4;
 
 __global__ __launch_bounds__(64 * K1_WAVES) void k1_spectrogram(
     const float2 *__restrict__ frames, int fl, int n, const float *__restrict__ window,
-    const float2 *__restrict__ twiddle, float *__restrict__ ps, int band_lo, int band_w) {
+    const float2 *__restrict__ twiddle, float *__restrict__ ps, int band_lo, int band_w,
+    int32_t *__restrict__ work_count) {
   __shared__ cpx tw_s[256];
   __shared__ cpx xch[K1_WAVES][XCHG_LEN];
 
@@ -32,6 +33,8 @@ __global__ __launch_bounds__(64 * K1_WAVES) void k1_spectrogram(
   const int L = tid & 63;
   const int wv = tid >> 6;
   const int b = blockIdx.y;
+  // K2 (next on the stream) appends to the coarse-search work list: reset its counter
+  if (blockIdx.x == 0 && b == 0 && tid == 0) *work_count = 0;
 
   tw_s[tid] = cpx{twiddle[tid].x, twiddle[tid].y};
   __syncthreads();
@@ -97,7 +100,7 @@ void launch_spectrogram(uwspr_ctx *c, const float *frames, int B) {
   dim3 grid((f.n + K1_WAVES * K1_ROWS_PER_WAVE - 1) / (K1_WAVES * K1_ROWS_PER_WAVE), B);
   hipLaunchKernelGGL(k1_spectrogram, grid, dim3(64 * K1_WAVES), 0, c->stream,
                      (const float2 *)frames, f.fl, f.n, c->d_window,
-                     (const float2 *)c->d_twiddle, c->d_ps, f.band_lo, f.band_w);
+                     (const float2 *)c->d_twiddle, c->d_ps, f.band_lo, f.band_w, c->d_work);
 }
 
 }  // namespace uwspr

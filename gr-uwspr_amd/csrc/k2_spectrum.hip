@@ -147,9 +147,8 @@ void launch_spectrum(uwspr_ctx *c, int B) {
   prof_scope ps(c, UWSPR_K_SPECTRUM, B);
   const size_t tile = (size_t)c->fc.n * c->fc.band_w * sizeof(float);
   const int stage = tile <= 60 * 1024;
-  (void)hipMemsetAsync(c->d_work, 0, sizeof(int32_t), c->stream);
   hipLaunchKernelGGL(k2_spectrum, dim3(B), dim3(K2_THREADS), stage ? tile : 0, c->stream, c->d_ps,
-                     c->fc, c->d_psavg, c->d_smraw, c->d_smspec, c->d_noise, c->d_cands, c->d_npk,
+                     c->fc, c->d_psavg, c->d_smraw, c->d_smspec, c->d_noise, c->cur_cands, c->cur_npk,
                      stage, c->d_work, c->d_work + 1);
 }
 

@@ -212,7 +212,7 @@ void launch_coarse(uwspr_ctx *c, int B) {
   const long long items_max = (long long)f.cand_slots * B;
   const int grid = (int)std::min<long long>(items_max, c->num_cus);
   hipLaunchKernelGGL(k3_coarse, dim3(grid), dim3(K3_THREADS), coarse_lds_bytes(f), c->stream,
-                     c->d_ps, f, c->d_off, c->d_umap, c->d_cands, c->d_work, c->d_syncgrid,
+                     c->d_ps, f, c->d_off, c->d_umap, c->cur_cands, c->d_work, c->d_syncgrid,
                      c->d_syncgrid ? c->grid_cap : 0);
 }
 

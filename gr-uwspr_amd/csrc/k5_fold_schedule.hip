@@ -77,25 +77,25 @@ __device__ __forceinline__ void k5_wave_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave(
-    const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p, int H, float symfac,
-    float *__restrict__ sync, uint8_t *__restrict__ symbols) {
-  __shared__ float4 str_all[K5W_WAVES][2][UWSPR_NSYM];   // [0]: magnitudes, [1]: (0,0,0,+-cmet)
-  __shared__ double q_all[K5W_WAVES][2][UWSPR_NSYM];     // fs/162, fs*fs/162
+struct k5_wave_lds {
+  float4 str[2][UWSPR_NSYM];   // [0]: magnitudes, [1]: (0,0,0,+-cmet)
+};
+struct k5_wave_lds_soft {
+  double q[2][UWSPR_NSYM];     // fs/162, fs*fs/162
+};
+
+// One wavefront folds hypothesis h; returns its sync metric in every lane.
+template <bool SOFT>
+__device__ __forceinline__ float fold_wave(const dev_hyp *__restrict__ hyps,
+                                           const float4 *__restrict__ p, int h, float symfac,
+                                           uint8_t *__restrict__ symbols, k5_wave_lds &L,
+                                           k5_wave_lds_soft *Q) {
   const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = blockIdx.x * K5W_WAVES + wv;
-  if (h >= H) return;  // wave-uniform
-  const bool soft = symbols != nullptr;
   if (hyps[h].frame < 0) {
-    if (lane == 0) sync[h] = -1e30f;
-    if (soft)
+    if (SOFT)
       for (int i = lane; i < UWSPR_NSYM; i += 64) symbols[(size_t)h * UWSPR_NSYM + i] = 0;
-    return;
+    return -1e30f;
   }
-  float4 *pf = str_all[wv][0];
-  float4 *sc = str_all[wv][1];
-  double *q1 = q_all[wv][0], *q2 = q_all[wv][1];
   float fs[3];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
@@ -104,14 +104,14 @@ __global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave(
     if (i < UWSPR_NSYM) {
       const float4 P = p[(size_t)h * UWSPR_NSYM + i];
       const bool bit = pr3_rt(i);
-      pf[i] = P;
+      L.str[0][i] = P;
       const float cmet = (P.y + P.w) - (P.x + P.z);   // cc:214
       // ss -/+ cmet == ss + (-/+cmet); the three +0 terms leave ss unchanged
-      sc[i] = make_float4(0.0f, 0.0f, 0.0f, bit ? cmet : -cmet);
+      L.str[1][i] = make_float4(0.0f, 0.0f, 0.0f, bit ? cmet : -cmet);
       fs[r] = bit ? P.w - P.y : P.z - P.x;            // cc:219,222
-      if (soft) {
-        q1[i] = (double)fs[r] / 162.0;                // cc:243
-        q2[i] = (double)(fs[r] * fs[r]) / 162.0;      // cc:244
+      if (SOFT) {
+        Q->q[0][i] = (double)fs[r] / 162.0;                // cc:243
+        Q->q[1][i] = (double)(fs[r] * fs[r]) / 162.0;      // cc:244
       }
     }
   }
@@ -119,20 +119,20 @@ __global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave(
   float acc = 0.0f;
   if (lane < 2) {
     // lane 0: totp = (((totp+p0)+p1)+p2)+p3 per symbol (cc:213); lane 1: ss (cc:215)
-    const float4 *st = str_all[wv][lane];
+    const float4 *st = L.str[lane];
 #pragma unroll 9
     for (int i = 0; i < UWSPR_NSYM; i++) {
       const float4 P = st[i];
       acc = acc + P.x; acc = acc + P.y; acc = acc + P.z; acc = acc + P.w;
     }
-  } else if (soft && lane < 4) {
-    const double *q = q_all[wv][lane - 2];
+  } else if (SOFT && lane < 4) {
+    const double *q = Q->q[lane - 2];
 #pragma unroll 9
     for (int i = 0; i < UWSPR_NSYM; i++) acc = (float)((double)acc + q[i]);
   }
   const float totp = __shfl(acc, 0), ss = __shfl(acc, 1);
-  if (lane == 0) sync[h] = ieee_divf(ss, totp);  // cc:226
-  if (soft) {
+  const float sync = ieee_divf(ss, totp);  // cc:226
+  if (SOFT) {
     const float fsum = __shfl(acc, 2), f2sum = __shfl(acc, 3);
     const float fac = ieee_sqrtf(f2sum - fsum * fsum);  // cc:246
 #pragma unroll
@@ -147,6 +147,21 @@ __global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave(
       }
     }
   }
+  k5_wave_fence();  // LDS image may be reused by the caller
+  return sync;
+}
+
+template <bool SOFT>
+__global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave(
+    const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p, int H, float symfac,
+    float *__restrict__ sync, uint8_t *__restrict__ symbols) {
+  __shared__ k5_wave_lds L[K5W_WAVES];
+  __shared__ k5_wave_lds_soft Q[SOFT ? K5W_WAVES : 1];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = blockIdx.x * K5W_WAVES + wv;
+  if (h >= H) return;  // wave-uniform
+  const float s = fold_wave<SOFT>(hyps, p, h, symfac, symbols, L[wv], SOFT ? &Q[wv] : nullptr);
+  if ((threadIdx.x & 63) == 0) sync[h] = s;
 }
 
 void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, float *sync,
@@ -154,8 +169,9 @@ void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, floa
   if (H <= 0) return;
   prof_scope ps(c, UWSPR_K_FOLD, H);
   if (H <= 65536) {
-    hipLaunchKernelGGL(k5_fold_wave, dim3((H + K5W_WAVES - 1) / K5W_WAVES), dim3(64 * K5W_WAVES), 0,
-                       c->stream, hyps, p, H, 50.0f, sync, symbols);
+    dim3 g((H + K5W_WAVES - 1) / K5W_WAVES), b(64 * K5W_WAVES);
+    if (symbols) hipLaunchKernelGGL(k5_fold_wave<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
+    else hipLaunchKernelGGL(k5_fold_wave<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
   } else {
     hipLaunchKernelGGL(k5_fold, dim3((H + 255) / 256), dim3(256), 0, c->stream, hyps, p, H, 50.0f,
                        sync, symbols);
@@ -248,17 +264,16 @@ __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
 }
 
 template <int STAGE>
-__global__ void k_sched_step(cand_state *__restrict__ state, const dev_hyp *__restrict__ hin,
-                             const float *__restrict__ sync, dev_hyp *__restrict__ hout,
-                             int nslots) {
-  const int slot = blockIdx.x * 256 + threadIdx.x;
-  if (slot >= nslots) return;
+__device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict__ state,
+                                                const dev_hyp *__restrict__ hin,
+                                                const float *sync_of_slot,
+                                                dev_hyp *__restrict__ hout) {
   cand_state st = state[slot];
   const bool live = st.frame >= 0;
   constexpr int NIN = STAGE == 1 ? 5 : STAGE == 2 ? 5 : STAGE == 3 ? 2 : STAGE == 4 ? 5 : 5;
   constexpr int NOUT = STAGE == 1 ? 5 : STAGE == 2 ? 2 : STAGE == 3 ? 5 : STAGE == 4 ? 5 : 17;
   const dev_hyp *hi = hin + (size_t)slot * NIN;
-  const float *sy = sync + (size_t)slot * NIN;
+  const float *sy = sync_of_slot;
   dev_hyp *ho = hout + (size_t)slot * NOUT;
 
   if (STAGE == 1) {
@@ -308,6 +323,24 @@ __global__ void k_sched_step(cand_state *__restrict__ state, const dev_hyp *__re
   state[slot] = st;
 }
 
+// Fold of a candidate's NIN hypotheses (one wavefront each) fused with the
+// schedule transition that consumes them: one workgroup per candidate slot.
+template <int STAGE>
+__global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__restrict__ hin,
+                             const float4 *__restrict__ p, float *__restrict__ sync,
+                             dev_hyp *__restrict__ hout, int nslots) {
+  constexpr int NIN = STAGE == 3 ? 2 : 5;
+  __shared__ k5_wave_lds L[NIN];
+  __shared__ float sy[NIN];
+  const int slot = blockIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = slot * NIN + wv;
+  const float s = fold_wave<false>(hin, p, h, 50.0f, nullptr, L[wv], nullptr);
+  if ((threadIdx.x & 63) == 0) { sy[wv] = s; sync[h] = s; }
+  __syncthreads();
+  if (threadIdx.x == 0) sched_step_body<STAGE>(slot, state, hin, sy, hout);
+}
+
 // out[slot]: state + per-try sync / rms / shift / symbols (cc:465-475)
 __global__ void k_sched_finish(const cand_state *__restrict__ state,
                                const dev_hyp *__restrict__ h5, const float *__restrict__ sync5,
@@ -342,6 +375,36 @@ __global__ void k_sched_finish(const cand_state *__restrict__ state,
     (&o->symbols[0][0])[e] = on ? sym5[(size_t)slot * UWSPR_NJIG * UWSPR_NSYM + e] : (uint8_t)0;
 }
 
+// Per-frame slab for the multi-GPU gather: {npk, pad[3]} | candidate_t[K] |
+// {f1, drift1, sync1, shift1} of the frame's top candidate.
+__global__ void k_pack_slabs(const uwspr_candidate *__restrict__ cands,
+                             const int32_t *__restrict__ npk, int maxfreqs,
+                             const uwspr_demod_out *__restrict__ dout, int per_frame, int K,
+                             uint8_t *__restrict__ slab, int B) {
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const int slab_bytes = 16 + K * 48 + 16;
+  uint32_t *out = reinterpret_cast<uint32_t *>(slab + (size_t)b * slab_bytes);
+  const int words = slab_bytes / 4;
+  const uint32_t *cw = reinterpret_cast<const uint32_t *>(cands + (size_t)b * maxfreqs);
+  const uint32_t *dw = reinterpret_cast<const uint32_t *>(dout + (size_t)b * per_frame);
+  const int n = npk[b];
+  for (int w = threadIdx.x; w < words; w += blockDim.x) {
+    uint32_t v = 0;
+    if (w == 0) v = (uint32_t)n;
+    else if (w >= 4 && w < 4 + K * 12) { const int k = (w - 4) / 12; v = (k < n && k < maxfreqs) ? cw[w - 4] : 0u; }
+    else if (w >= 4 + K * 12) v = dw[w - 4 - K * 12];
+    out[w] = v;
+  }
+}
+
+void launch_pack_slabs(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t *npk,
+                       const uwspr_demod_out *dout, int per_frame, int K, uint8_t *slab, int B) {
+  prof_scope ps(c, UWSPR_K_SCHED, B);
+  hipLaunchKernelGGL(k_pack_slabs, dim3(B), dim3(128), 0, c->stream, cands, npk, c->fc.maxfreqs,
+                     dout, per_frame, K, slab, B);
+}
+
 void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t *npk,
                        int cand_stride, int B, int per_frame) {
   const int nslots = B * per_frame;
@@ -350,19 +413,20 @@ void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t
                      npk, cand_stride, B, per_frame, (float)c->p.cf, c->d_state, c->d_hyps);
 }
 
-// hyps of consecutive stages ping-pong between the two halves of d_hyps
-void launch_sched_step(uwspr_ctx *c, int stage, int nslots) {
-  prof_scope ps(c, UWSPR_K_SCHED, nslots);
+// hyps of consecutive stages ping-pong between the two halves of d_hyps;
+// stage s consumes the tone magnitudes K4 just wrote for the hypotheses of stage s-1
+void launch_fold_step(uwspr_ctx *c, int stage, int nslots) {
+  prof_scope ps(c, UWSPR_K_FOLD, (int64_t)nslots * (stage == 3 ? 2 : 5));
   dev_hyp *half0 = c->d_hyps, *half1 = c->d_hyps + (size_t)nslots * UWSPR_NJIG;
   dev_hyp *hin = (stage & 1) ? half0 : half1;
   dev_hyp *hout = (stage & 1) ? half1 : half0;
-  dim3 g((nslots + 255) / 256), b(256);
+  dim3 g(nslots);
   switch (stage) {
-    case 1: hipLaunchKernelGGL(k_sched_step<1>, g, b, 0, c->stream, c->d_state, hin, c->d_sync, hout, nslots); break;
-    case 2: hipLaunchKernelGGL(k_sched_step<2>, g, b, 0, c->stream, c->d_state, hin, c->d_sync, hout, nslots); break;
-    case 3: hipLaunchKernelGGL(k_sched_step<3>, g, b, 0, c->stream, c->d_state, hin, c->d_sync, hout, nslots); break;
-    case 4: hipLaunchKernelGGL(k_sched_step<4>, g, b, 0, c->stream, c->d_state, hin, c->d_sync, hout, nslots); break;
-    default: hipLaunchKernelGGL(k_sched_step<5>, g, b, 0, c->stream, c->d_state, hin, c->d_sync, hout, nslots); break;
+    case 1: hipLaunchKernelGGL(k5_fold_step<1>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, nslots); break;
+    case 2: hipLaunchKernelGGL(k5_fold_step<2>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, nslots); break;
+    case 3: hipLaunchKernelGGL(k5_fold_step<3>, g, dim3(128), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, nslots); break;
+    case 4: hipLaunchKernelGGL(k5_fold_step<4>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, nslots); break;
+    default: hipLaunchKernelGGL(k5_fold_step<5>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, nslots); break;
   }
 }
 
@@ -371,7 +435,7 @@ void launch_sched_finish(uwspr_ctx *c, int nslots) {
   // stage-5 hyps live in the half selected by (5 & 1) -> half1
   dev_hyp *h5 = c->d_hyps + (size_t)nslots * UWSPR_NJIG;
   hipLaunchKernelGGL(k_sched_finish, dim3(nslots), dim3(256), 0, c->stream, c->d_state, h5,
-                     c->d_sync, c->d_sym, c->d_dout, nslots);
+                     c->d_sync, c->d_sym, c->cur_dout, nslots);
 }
 
 }  // namespace uwspr

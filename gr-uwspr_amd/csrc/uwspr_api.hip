@@ -51,7 +51,7 @@ static int ensure(uwspr_ctx *c, T **buf, size_t *cap, size_t need_elems) {
 }
 
 prof_scope::prof_scope(uwspr_ctx *cx, int kind, int64_t units) : c(cx), idx(-1) {
-  if (!c->prof_on) return;
+  if (!(c->prof_mask & (1 << kind))) return;
   ev_pair p;
   auto get = [&]() {
     hipEvent_t e;
@@ -98,7 +98,9 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->cap_hyps = 0; c->d_hyps = nullptr; c->cap_abi_hyps = 0; c->d_abi_hyps = nullptr;
   c->cap_p = 0; c->d_p = nullptr; c->cap_sync = 0; c->d_sync = nullptr;
   c->cap_sym = 0; c->d_sym = nullptr; c->cap_state = 0; c->d_state = nullptr;
-  c->cap_dout = 0; c->d_dout = nullptr; c->prof_on = false;
+  c->cap_dout = 0; c->d_dout = nullptr; c->prof_mask = 0;
+  c->cur_cands = nullptr; c->cur_npk = nullptr; c->cur_dout = nullptr; c->last_per_frame = 0;
+  c->cap_slab = 0; c->d_slab = nullptr;
   *out = c;  // handed back even on failure so uwspr_last_error() can be read
 
   fdr_consts &f = c->fc;
@@ -246,7 +248,7 @@ extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
   void *bufs[] = {c->d_window, c->d_twiddle, c->d_off, c->d_umap, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
                   c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps,
-                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout};
+                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab};
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (auto &e : c->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -347,9 +349,12 @@ static int ensure_fdr(uwspr_ctx *c, int B) {
   return UWSPR_OK;
 }
 
-static int run_fdr(uwspr_ctx *c, const float *dframes, int B) {
+static int run_fdr(uwspr_ctx *c, const float *dframes, int B, uwspr_candidate *user_cands = nullptr,
+                   int32_t *user_npk = nullptr) {
   int rc = ensure_fdr(c, B);
   if (rc) return rc;
+  c->cur_cands = user_cands ? user_cands : c->d_cands;
+  c->cur_npk = user_npk ? user_npk : c->d_npk;
   if (c->grid_cap > 0) {
     size_t cap = c->cap_grid_bytes / sizeof(float);
     rc = ensure(c, &c->d_syncgrid, &cap, (size_t)B * c->grid_cap * c->fc.ntot);
@@ -370,9 +375,12 @@ extern "C" int uwspr_fdr_batch(uwspr_ctx *c, const float *frames, int B, int whe
   if (rc) return rc;
   const float *d;
   if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
-  if ((rc = run_fdr(c, d, B))) return rc;
-  if ((rc = copy_out(c, cands, c->d_cands, (size_t)B * c->fc.maxfreqs * sizeof(uwspr_candidate), where))) return rc;
-  if ((rc = copy_out(c, npk, c->d_npk, (size_t)B * sizeof(int32_t), where))) return rc;
+  const bool direct = where == UWSPR_DEVICE && cands && npk;
+  if ((rc = run_fdr(c, d, B, direct ? cands : nullptr, direct ? npk : nullptr))) return rc;
+  if (!direct) {
+    if ((rc = copy_out(c, cands, c->d_cands, (size_t)B * c->fc.maxfreqs * sizeof(uwspr_candidate), where))) return rc;
+    if ((rc = copy_out(c, npk, c->d_npk, (size_t)B * sizeof(int32_t), where))) return rc;
+  }
   if (where == UWSPR_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWSPR_OK;
 }
@@ -531,7 +539,8 @@ extern "C" int uwspr_sync_and_demodulate_batch(uwspr_ctx *c, const float *frames
 
 // ------------------------------------------------------ refinement schedule
 static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_candidate *dcands,
-                        const int32_t *dnpk, int cand_stride, int per_frame) {
+                        const int32_t *dnpk, int cand_stride, int per_frame,
+                        uwspr_demod_out *user_out = nullptr) {
   static const int hpc[6] = {5, 5, 2, 5, 5, UWSPR_NJIG};
   const size_t nslots = (size_t)B * per_frame;
   int rc;
@@ -539,15 +548,19 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
   if ((rc = ensure(c, &c->d_hyps, &c->cap_hyps, 2 * nslots * UWSPR_NJIG))) return rc;
   if ((rc = ensure_sweep(c, nslots * UWSPR_NJIG, true))) return rc;
   if ((rc = ensure(c, &c->d_dout, &c->cap_dout, nslots))) return rc;
+  c->cur_dout = user_out ? user_out : c->d_dout;
   dev_hyp *half[2] = {c->d_hyps, c->d_hyps + nslots * UWSPR_NJIG};
   launch_sched_init(c, dcands, dnpk, cand_stride, B, per_frame);
   for (int s = 0; s < 6; s++) {
     const int H = (int)(nslots * hpc[s]);
     const dev_hyp *h = half[s & 1];
     launch_tonecorr(c, dframes, B, h, H, c->d_p);
-    launch_fold(c, h, c->d_p, H, c->d_sync, s == 5 ? c->d_sym : nullptr);
-    if (s < 5) launch_sched_step(c, s + 1, (int)nslots);
-    else launch_sched_finish(c, (int)nslots);
+    if (s < 5) {
+      launch_fold_step(c, s + 1, (int)nslots);   // fold of stage s + transition to stage s+1
+    } else {
+      launch_fold(c, h, c->d_p, H, c->d_sync, c->d_sym);
+      launch_sched_finish(c, (int)nslots);
+    }
   }
   HIPCHK(c, hipGetLastError());
   return UWSPR_OK;
@@ -589,20 +602,48 @@ extern "C" int uwspr_pipeline_batch(uwspr_ctx *c, const float *frames, int B, in
   if (max_per_frame <= 0) return fail(c, UWSPR_ERR_ARG, "max_per_frame=%d", max_per_frame);
   const float *d;
   if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
-  if ((rc = run_fdr(c, d, B))) return rc;
-  if ((rc = run_schedule(c, d, B, c->d_cands, c->d_npk, c->fc.maxfreqs, max_per_frame))) return rc;
-  if ((rc = copy_out(c, cands, c->d_cands, (size_t)B * c->fc.maxfreqs * sizeof(uwspr_candidate), where))) return rc;
-  if ((rc = copy_out(c, npk, c->d_npk, (size_t)B * sizeof(int32_t), where))) return rc;
-  if ((rc = copy_out(c, out, c->d_dout, (size_t)B * max_per_frame * sizeof(uwspr_demod_out), where))) return rc;
+  // device callers get the results written straight into their buffers
+  const bool dev = where == UWSPR_DEVICE;
+  if ((rc = run_fdr(c, d, B, dev ? cands : nullptr, (dev && cands) ? npk : nullptr))) return rc;
+  if ((rc = run_schedule(c, d, B, c->cur_cands, c->cur_npk, c->fc.maxfreqs, max_per_frame,
+                         dev ? out : nullptr))) return rc;
+  c->last_per_frame = max_per_frame;
+  if (c->cur_cands == c->d_cands &&
+      (rc = copy_out(c, cands, c->d_cands, (size_t)B * c->fc.maxfreqs * sizeof(uwspr_candidate), where))) return rc;
+  if (c->cur_npk == c->d_npk && (rc = copy_out(c, npk, c->d_npk, (size_t)B * sizeof(int32_t), where))) return rc;
+  if (c->cur_dout == c->d_dout &&
+      (rc = copy_out(c, out, c->d_dout, (size_t)B * max_per_frame * sizeof(uwspr_demod_out), where))) return rc;
   if (where == UWSPR_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWSPR_OK;
 }
 
-// -------------------------------------------------------------- profiling
-extern "C" int uwspr_prof_enable(uwspr_ctx *c, int on) {
+extern "C" int uwspr_pack_slabs(uwspr_ctx *c, int B, int K, void *slabs, int where) {
   int rc = ready(c);
   if (rc) return rc;
-  c->prof_on = on != 0;
+  if (!slabs || K < 1 || K > c->fc.maxfreqs || B <= 0 || B > c->last_B || c->last_per_frame < 1 || !c->cur_dout)
+    return fail(c, UWSPR_ERR_ARG, "uwspr_pack_slabs: needs a preceding uwspr_pipeline_batch of >= %d frames", B);
+  const size_t bytes = (size_t)B * (16 + (size_t)K * 48 + 16);
+  uint8_t *dst = (uint8_t *)slabs;
+  if (where == UWSPR_HOST) {
+    size_t cap = c->cap_slab;
+    if ((rc = ensure(c, &c->d_slab, &cap, bytes))) return rc;
+    c->cap_slab = cap;
+    dst = c->d_slab;
+  }
+  launch_pack_slabs(c, c->cur_cands, c->cur_npk, c->cur_dout, c->last_per_frame, K, dst, B);
+  HIPCHK(c, hipGetLastError());
+  if (where == UWSPR_HOST) {
+    HIPCHK(c, hipMemcpyAsync(slabs, c->d_slab, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return UWSPR_OK;
+}
+
+// -------------------------------------------------------------- profiling
+extern "C" int uwspr_prof_enable(uwspr_ctx *c, int mask) {
+  int rc = ready(c);
+  if (rc) return rc;
+  c->prof_mask = mask & UWSPR_PROF_ALL;
   return UWSPR_OK;
 }
 

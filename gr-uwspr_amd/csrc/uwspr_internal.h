@@ -98,8 +98,12 @@ struct uwspr_ctx {
   size_t cap_sym; uint8_t *d_sym;                 // [H][162]
   size_t cap_state; uwspr::cand_state *d_state;
   size_t cap_dout; uwspr_demod_out *d_dout;
+  // buffers the current call writes (the context's own, or the caller's device memory)
+  uwspr_candidate *cur_cands; int32_t *cur_npk; uwspr_demod_out *cur_dout;
+  int last_per_frame;
+  size_t cap_slab; uint8_t *d_slab;
 
-  bool prof_on;
+  int prof_mask;
   std::vector<uwspr::ev_pair> prof_events;
   std::vector<hipEvent_t> ev_pool;
 };
@@ -118,7 +122,9 @@ void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, floa
 // schedule stages; see k5_schedule.hip
 void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t *npk,
                        int cand_stride, int B, int per_frame);
-void launch_sched_step(uwspr_ctx *c, int stage, int ncand);
+void launch_fold_step(uwspr_ctx *c, int stage, int ncand);
+void launch_pack_slabs(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t *npk,
+                       const uwspr_demod_out *dout, int per_frame, int K, uint8_t *slab, int B);
 void launch_sched_finish(uwspr_ctx *c, int ncand);
 
 // profiling brackets

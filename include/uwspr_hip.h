@@ -209,6 +209,13 @@ int uwspr_pipeline_batch(uwspr_ctx *ctx, const float *frames, int B, int where,
                          int max_per_frame, uwspr_candidate *cands,
                          int32_t *npk, uwspr_demod_out *out);
 
+/* Multi-GPU hand-off: packs the results of the LAST uwspr_pipeline_batch into
+ * one fixed-size slab per frame, ready for a gather to the root rank:
+ *   int32 npk, 12 pad bytes | candidate_t[K] (first K candidates, zero-filled past npk)
+ *   | float f1, drift1, sync1; int32 shift1 of the frame's top candidate
+ * = 32 + 48*K bytes per frame; slabs: [B][32+48K]. */
+int uwspr_pack_slabs(uwspr_ctx *ctx, int B, int K, void *slabs, int where);
+
 /* ---- measurement -------------------------------------------------------- */
 enum { UWSPR_K_SPECTROGRAM = 0, UWSPR_K_SPECTRUM = 1, UWSPR_K_COARSE = 2,
        UWSPR_K_TONECORR = 3, UWSPR_K_FOLD = 4, UWSPR_K_SCHED = 5, UWSPR_K_COUNT = 6 };
@@ -217,9 +224,13 @@ typedef struct uwspr_prof {
   int64_t launches[UWSPR_K_COUNT];
   int64_t units[UWSPR_K_COUNT];    /* frames (K0,K1), candidates (K2), hypotheses (K3,K4) */
 } uwspr_prof;
-/* HIP events are recorded around every kernel launch on the context's stream
- * while enabled; uwspr_prof_read synchronises, sums and resets them. */
-int uwspr_prof_enable(uwspr_ctx *ctx, int on);
+/* HIP events are recorded around the kernel launches of the selected families on
+ * the context's stream; uwspr_prof_read synchronises, sums and resets them.
+ * mask: bit (1 << UWSPR_K_*) per family, UWSPR_PROF_ALL for all, 0 = off.
+ * (Each recorded event is a marker packet on the queue: measuring only the
+ * dominant kernel keeps the timed region close to the unobserved one.) */
+#define UWSPR_PROF_ALL 0x3f
+int uwspr_prof_enable(uwspr_ctx *ctx, int mask);
 int uwspr_prof_read(uwspr_ctx *ctx, uwspr_prof *out);
 
 /* ---- host-side tail of the path ------------------ */

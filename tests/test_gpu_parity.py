@@ -240,6 +240,35 @@ def test_pipeline_device_pointers_equal_host_pointers(ctx, G, frames):
     assert o1.tobytes() == o2.tobytes()
 
 
+def test_gather_slabs_kernel_matches_reference_packing(ctx, G, frames):
+    """uwspr_pack_slabs (what bench.py gathers across ranks) == dist.pack_slabs."""
+    import torch
+    from gr_uwspr_amd import dist as D
+    N = G.native
+    dev = torch.from_numpy(frames).cuda()
+    B = frames.shape[0]
+    cands_t = torch.empty(B * ctx.maxfreqs * 48, dtype=torch.uint8, device="cuda")
+    npk_t = torch.empty(B, dtype=torch.int32, device="cuda")
+    out_t = torch.empty(B * N.DEMOD_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    slab_t = torch.empty((B, D.SLAB_BYTES), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.pipeline_batch_into(dev, cands_t, npk_t, out_t, max_per_frame=1)
+    ctx.pack_slabs_into(B, D.SLAB_K, slab_t)
+    ctx.synchronize()
+    ref = D.pack_slabs(cands_t, npk_t, out_t, ctx.maxfreqs, 1, N.DEMOD_DTYPE.itemsize)
+    got = slab_t.cpu().numpy()
+    refn = ref.cpu().numpy()
+    npk = npk_t.cpu().numpy()
+    for b in range(B):
+        k = min(int(npk[b]), D.SLAB_K)
+        assert (got[b, :16 + 48 * k] == refn[b, :16 + 48 * k]).all()
+        assert not got[b, 16 + 48 * k:16 + 48 * D.SLAB_K].any()      # zero-filled past npk
+        assert (got[b, 16 + 48 * D.SLAB_K:] == refn[b, 16 + 48 * D.SLAB_K:]).all()
+    host = np.zeros((B, D.SLAB_BYTES), np.uint8)
+    ctx.pack_slabs_into(B, D.SLAB_K, host)
+    assert (host == got).all()
+
+
 def test_full_size_properties_256_frames(ctx, G):
     """BASELINE configs[1] size: 256 frames.  Size-independent properties:
     (1) batch result == per-frame result (frames are independent),
