@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
   constexpr int PPW = 16 * T;        // pairs per wavefront
   constexpr int LPP = 4 / T;         // lanes per pair
   constexpr int NLD = PPW / 4;       // cooperative loads per lane per chunk
-  __shared__ float lds_all[K4_WAVES][PPW * K4_ROWDW];
+  __shared__ __align__(16) float lds_all[K4_WAVES][PPW * K4_ROWDW];
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -102,15 +102,21 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
       // delta[] = {-1.5,-0.5,0.5,1.5} * (float)(375/256), cc:148 (exact in binary32)
       const float delta = ((float)(tone0 + j) - 1.5f) * 1.46484375f;
       const double ang = kTwoPiDt * (double)(fp + delta);
+#ifdef K4_EXPERIMENT_FASTTRIG   // timing experiment only: NOT the reference arithmetic
+      cd[j] = __cosf((float)ang); sd[j] = __sinf((float)ang);
+#else
       double sn, cs;
       sincos(ang, &sn, &cs);
       cd[j] = (float)cs;
       sd[j] = (float)sn;
+#endif
     }
   }
 
   // ---- cooperative loader geometry ---------------------------------------
-  // load t (0..NLD-1) of a chunk: window seg = 4t + lane/16, sample kk = lane%16
+  // load t (0..NLD-1) of a chunk: window seg = 4t + lane/16, sample kk = lane%16.
+  // (16-byte loads were tried: sample addresses are only 8-byte aligned and
+  // unaligned dwordx4 loads ran 1.15-1.9x slower on gfx950.)
   const int kk = lane & 15;
   const int segq = lane >> 4;
   const float2 *src[NLD];  // sample 0 (+kk) of that window, fast path
@@ -125,6 +131,10 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
 
   float2 stage[NLD];
   auto load_chunk = [&](int c) {
+#ifdef K4_EXPERIMENT_NOLOAD   // timing experiment only
+    for (int t = 0; t < NLD; t++) stage[t] = make_float2(0.5f + c, 0.25f);
+    return;
+#endif
     if (interior) {
 #pragma unroll
       for (int t = 0; t < NLD; t++) stage[t] = src[t][16 * c];
@@ -189,8 +199,7 @@ static int k4_choose_t(long long pairs) {
   }
   if (forced == 1 || forced == 2 || forced == 4) return forced;
   // enough wavefronts to fill 256 CUs x 4 SIMDs several times over -> amortise
-  if (pairs >= 4LL * 1024 * 1024) return 4;
-  if (pairs >= 1024 * 1024) return 2;
+  if (pairs >= 1024 * 1024) return 2;   // T=4 (2 waves/SIMD at 200+ VGPRs) measured no faster
   return 1;
 }
 
@@ -208,6 +217,199 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
   if (T == 1) hipLaunchKernelGGL(k4_tonecorr<1>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, hyps, H, po);
   else if (T == 2) hipLaunchKernelGGL(k4_tonecorr<2>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, hyps, H, po);
   else hipLaunchKernelGGL(k4_tonecorr<4>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, hyps, H, po);
+}
+
+}  // namespace uwspr
+
+// ---------------------------------------------------------------------------
+// Lag-group form.  The reference's lag sweeps (mode 0, cc:165; the 17 jiggered
+// shifts cc:457-468) and any (freq, lag, drift) grid evaluate several time lags
+// at the SAME per-symbol frequencies: the tone phasor tables c[j][k], s[j][k]
+// (cc:186-199) are identical for all of them -- the reference itself caches them
+// across lags via `fplast`.  Here a lane owns one (group, symbol) pair and one
+// tone, advances that tone's phasor once per sample, and accumulates inp/quad
+// for all NL lags of the group against it: 6 + 8*NL ops per sample instead of
+// 14*NL, every accumulator still seeing the reference's exact operation order.
+// LDS rows are (lag, pair); the loader brings 16 samples per row per chunk.
+namespace uwspr {
+
+constexpr int K4G_WAVES = 2;
+
+template <int NL>
+__global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
+    const float2 *__restrict__ frames, int fl, int nframes, const dev_grp *__restrict__ grps,
+    int G, float *__restrict__ p_out) {
+  constexpr int PPW = 16;                  // (group, symbol) pairs per wavefront, 4 tone lanes each
+  constexpr int NLP = (NL + 1) & ~1;       // lags per sample slot, padded to even (16-B aligned slots)
+  constexpr int ROWDW = 32 * NLP + 4;      // dwords per pair row: [16 samples][NLP lags] float2 + 16 B pad
+  constexpr int NLD = 4 * NL;              // cooperative loads per lane per chunk
+  __shared__ __align__(16) float lds_all[K4G_WAVES][PPW * ROWDW];
+
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float *lds = lds_all[wv];
+
+  const long long total = (long long)G * UWSPR_NSYM;
+  const long long g0 = ((long long)blockIdx.x * K4G_WAVES + wv) * PPW;
+  if (g0 >= total) return;  // wave-uniform
+
+  const int gA = (int)(g0 / UWSPR_NSYM);
+  const int iA0 = (int)(g0 - (long long)gA * UWSPR_NSYM);
+  const int sb = min(PPW, UWSPR_NSYM - iA0);  // pairs < sb belong to group gA
+  const dev_grp A = grps[gA];
+  const dev_grp Bg = grps[min(gA + 1, G - 1)];
+  const bool okA = A.frame >= 0 && A.frame < nframes;
+  const bool okB = (gA + 1 < G) && Bg.frame >= 0 && Bg.frame < nframes;
+  const int frA = okA ? A.frame : 0, frB = okB ? Bg.frame : 0;
+  const int nvA = okA ? A.nvalid : 0, nvB = okB ? Bg.nvalid : 0;
+  // lag of slot l for the two groups; skipped groups / unused slots point at safe samples
+  int la[NL], lb[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    la[l] = l < nvA ? A.lag[l] : (nvA > 0 ? A.lag[0] : 1 - 256 * iA0);
+    lb[l] = l < nvB ? Bg.lag[l] : (nvB > 0 ? Bg.lag[0] : 1);
+  }
+
+  const int pr = lane >> 2;
+  const int tone = lane & 3;
+  const bool mineA = pr < sb;
+  const int own_i = mineA ? iA0 + pr : pr - sb;
+  bool inside = true;
+#pragma unroll
+  for (int l = 0; l < NL; l++) {
+    const int nb = (mineA ? la[l] : lb[l]) + 256 * own_i;
+    inside = inside && (nb > 0) && (nb + 255 < fl);
+  }
+  const bool interior = __all(inside);
+
+  // ---- this lane's tone phasor step (binary64 angle, cc:173-189) ------------
+  float cd, sd;
+  {
+    const dev_grp &gy = mineA ? A : Bg;
+    float fp;
+    if (gy.m_type == UWSPR_LINEAR) {
+      fp = (float)((double)gy.f0 +
+                   ((double)gy.drift / 2.0) * ((double)(float)own_i - 81.0) / 81.0);
+    } else {
+      fp = gy.f0 + gy.slmc;
+    }
+    const float delta = ((float)tone - 1.5f) * 1.46484375f;
+    double sn, cs;
+    sincos(kTwoPiDt * (double)(fp + delta), &sn, &cs);
+    cd = (float)cs;
+    sd = (float)sn;
+  }
+
+  // ---- cooperative loader: load t = (lag t/4, pair slot 4(t%4) + lane/16), sample lane%16
+  const int kk = lane & 15;
+  const int segq = lane >> 4;
+  // element offsets relative to the wave's first frame (wave-uniform base pointer)
+  const float2 *wbase = frames + (long long)frA * fl;
+  int eoff[4];
+  bool slotA[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int pj = 4 * j + segq;
+    slotA[j] = pj < sb;
+    eoff[j] = slotA[j] ? 256 * (iA0 + pj) + kk : (frB - frA) * fl + 256 * (pj - sb) + kk;
+  }
+  // rows whose frame is further than 2^31 samples from the first one take the general path
+  const bool near = ((long long)(frB - frA) * fl < (1LL << 30)) && ((long long)(frB - frA) * fl > -(1LL << 30));
+
+  const bool fast = interior && near;  // wave-uniform
+  float2 stage[NLD];
+  auto load_chunk = [&](int c) {
+    if (fast) {
+#pragma unroll
+      for (int t = 0; t < NLD; t++) {
+        const int l = t >> 2, j = t & 3;
+        stage[t] = wbase[eoff[j] + (slotA[j] ? la[l] : lb[l]) + 16 * c];
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NLD; t++) {
+        const int l = t >> 2, j = t & 3;
+        const int lag = slotA[j] ? la[l] : lb[l];
+        const int n = (slotA[j] ? 256 * (iA0 + 4 * j + segq) : 256 * (4 * j + segq - sb)) + kk + lag + 16 * c;
+        const bool inr = (n > 0) && (n < fl);  // cc:205, sample 0 excluded
+        const long long fb = (long long)(slotA[j] ? frA : frB) * fl;
+        const float2 v = frames[fb + min(max(n, 0), fl - 1)];
+        stage[t] = inr ? v : make_float2(0.0f, 0.0f);
+      }
+    }
+  };
+
+  float c = 1.0f, s = 0.0f;
+  float inp[NL], quad[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) { inp[l] = 0.0f; quad[l] = 0.0f; }
+
+  load_chunk(0);
+  for (int ch = 0; ch < 16; ch++) {
+    wave_lds_fence();
+#pragma unroll
+    for (int t = 0; t < NLD; t++) {
+      const int l = t >> 2, j = t & 3;
+      *reinterpret_cast<float2 *>(&lds[(4 * j + segq) * ROWDW + (kk * NLP + l) * 2]) = stage[t];
+    }
+    wave_lds_fence();
+    if (ch < 15) load_chunk(ch + 1);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      // the NL lags of this sample slot are contiguous: 16-byte reads
+      const float *slot = &lds[pr * ROWDW + k * NLP * 2];
+      float2 x[NLP];
+#pragma unroll
+      for (int q = 0; q < NLP / 2; q++) {
+        if (2 * q + 1 < NL || (NL & 1) == 0) {
+          const float4 v = *reinterpret_cast<const float4 *>(slot + 4 * q);
+          x[2 * q] = make_float2(v.x, v.y); x[2 * q + 1] = make_float2(v.z, v.w);
+        } else {
+          x[2 * q] = *reinterpret_cast<const float2 *>(slot + 4 * q);
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        inp[l] = (inp[l] + x[l].x * c) + x[l].y * s;     // cc:206
+        quad[l] = (quad[l] - x[l].x * s) + x[l].y * c;   // cc:207
+      }
+      const float nc = c * cd - s * sd;                  // cc:193-195
+      const float ns = c * sd + s * cd;
+      c = nc; s = ns;
+    }
+  }
+
+  if (g0 + pr < total) {
+    const int nv = mineA ? nvA : nvB;
+    const int hb = mineA ? A.hyp_base : Bg.hyp_base;
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      if (l < nv) {
+        const float pj = ieee_sqrtf(inp[l] * inp[l] + quad[l] * quad[l]);  // cc:211
+        p_out[((long long)(hb + l) * UWSPR_NSYM + own_i) * 4 + tone] = pj;
+      }
+    }
+    // groups that are skipped produce zeros for their hypotheses
+    const dev_grp &gy = mineA ? A : Bg;
+    if (!(mineA ? okA : okB) && gy.nvalid > 0)
+      for (int l = 0; l < gy.nvalid && l < NL; l++)
+        p_out[((long long)(gy.hyp_base + l) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
+  }
+}
+
+void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
+                            int NL, int64_t nhyps, float4 *p) {
+  if (G <= 0) return;
+  prof_scope ps(c, UWSPR_K_TONECORR, nhyps);
+  const long long total = (long long)G * UWSPR_NSYM;
+  const long long waves = (total + 15) / 16;
+  const unsigned blocks = (unsigned)((waves + K4G_WAVES - 1) / K4G_WAVES);
+  const float2 *fr = (const float2 *)frames;
+  float *po = (float *)p;
+  dim3 blk(64 * K4G_WAVES);
+  if (NL == 5) hipLaunchKernelGGL(k4_group<5>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, grps, G, po);
+  else if (NL == 6) hipLaunchKernelGGL(k4_group<6>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, grps, G, po);
+  else hipLaunchKernelGGL(k4_group<8>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, grps, G, po);
 }
 
 }  // namespace uwspr

@@ -221,6 +221,15 @@ __device__ inline void emit(dev_hyp *h, const cand_state &st, bool on, int lag, 
   h->lag = lag; h->f0 = f0; h->drift = drift; h->slmc = st.slmc; h->m_type = st.m_type;
 }
 
+// the same hypotheses as a lag group (shared phasors in K4)
+__device__ inline void emit_group(dev_grp *g, const cand_state &st, bool on, float f0, float drift,
+                                  int hyp_base, const int *lags, int n) {
+  g->frame = on ? st.frame : -1;
+  g->m_type = st.m_type; g->f0 = f0; g->drift = drift; g->slmc = st.slmc;
+  g->nvalid = n; g->hyp_base = hyp_base; g->_pad = 0;
+  for (int l = 0; l < 8; l++) g->lag[l] = l < n ? lags[l] : lags[0];
+}
+
 // cc:227-231 over a list scanned in order: strict >, defaults -1e30 / 0 / 0.0
 struct best3 { float sync; int shift; float f; };
 __device__ inline best3 best_of(const float *sy, const dev_hyp *hy, int n) {
@@ -233,7 +242,7 @@ __device__ inline best3 best_of(const float *sy, const dev_hyp *hy, int n) {
 __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
                              const int32_t *__restrict__ npk, int cand_stride, int B,
                              int per_frame, float cf, cand_state *__restrict__ state,
-                             dev_hyp *__restrict__ hyps) {
+                             dev_hyp *__restrict__ hyps, dev_grp *__restrict__ grps) {
   const int slot = blockIdx.x * 256 + threadIdx.x;
   if (slot >= B * per_frame) return;
   const int b = slot / per_frame, j = slot - b * per_frame;
@@ -260,14 +269,20 @@ __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
   // S0 (cc:409-415): mode 0, lag = shift1-128 .. shift1+128 step 64, f0 = f1 + 0*0.0f
   dev_hyp *h = hyps + (size_t)slot * 5;
   const float f0 = st.f1 + (float)0 * 0.0f;
-  for (int q = 0; q < 5; q++) emit(&h[q], st, on, st.shift1 - 128 + 64 * q, f0, st.drift1);
+  int lags[5];
+  for (int q = 0; q < 5; q++) {
+    lags[q] = st.shift1 - 128 + 64 * q;
+    emit(&h[q], st, on, lags[q], f0, st.drift1);
+  }
+  emit_group(&grps[slot], st, on, f0, st.drift1, slot * 5, lags, 5);
 }
 
 template <int STAGE>
 __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict__ state,
                                                 const dev_hyp *__restrict__ hin,
                                                 const float *sync_of_slot,
-                                                dev_hyp *__restrict__ hout) {
+                                                dev_hyp *__restrict__ hout,
+                                                dev_grp *__restrict__ grps) {
   cand_state st = state[slot];
   const bool live = st.frame >= 0;
   constexpr int NIN = STAGE == 1 ? 5 : STAGE == 2 ? 5 : STAGE == 3 ? 2 : STAGE == 4 ? 5 : 5;
@@ -303,8 +318,12 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     }
     st.worth = (live && st.sync1 > 0.10f) ? 1 : 0;
     const float f0 = st.f1 + (float)0 * 0.0f;
-    for (int q = 0; q < 5; q++)
-      emit(&ho[q], st, st.worth != 0, st.shift1 - 32 + 16 * q, f0, st.drift1);
+    int lags[5];
+    for (int q = 0; q < 5; q++) {
+      lags[q] = st.shift1 - 32 + 16 * q;
+      emit(&ho[q], st, st.worth != 0, lags[q], f0, st.drift1);
+    }
+    emit_group(&grps[slot], st, st.worth != 0, f0, st.drift1, slot * 5, lags, 5);
   } else if (STAGE == 4) {
     // after S3 -> S4 (cc:449-452): f = f1 + ifreq*0.05
     if (st.worth) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
@@ -313,12 +332,18 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
   } else {
     // after S4 -> S5 (cc:457-468): 17 jiggered shifts, mode 2
     if (st.worth) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
+    int lags[18];
     for (int idt = 0; idt < UWSPR_NJIG; idt++) {
       int ii = (idt + 1) / 2;
       if (idt % 2 == 1) ii = -ii;
       ii = 8 * ii;
-      emit(&ho[idt], st, st.worth != 0, st.shift1 + ii, st.f1, st.drift1);
+      lags[idt] = st.shift1 + ii;
+      emit(&ho[idt], st, st.worth != 0, lags[idt], st.f1, st.drift1);
     }
+    lags[17] = lags[16];
+    for (int g = 0; g < 3; g++)  // 17 jiggered shifts as three lag groups of 6, 6, 5
+      emit_group(&grps[slot * 3 + g], st, st.worth != 0, st.f1, st.drift1,
+                 slot * UWSPR_NJIG + 6 * g, lags + 6 * g, g < 2 ? 6 : 5);
   }
   state[slot] = st;
 }
@@ -328,7 +353,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
 template <int STAGE>
 __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__restrict__ hin,
                              const float4 *__restrict__ p, float *__restrict__ sync,
-                             dev_hyp *__restrict__ hout, int nslots) {
+                             dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps, int nslots) {
   constexpr int NIN = STAGE == 3 ? 2 : 5;
   __shared__ k5_wave_lds L[NIN];
   __shared__ float sy[NIN];
@@ -338,7 +363,7 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
   const float s = fold_wave<false>(hin, p, h, 50.0f, nullptr, L[wv], nullptr);
   if ((threadIdx.x & 63) == 0) { sy[wv] = s; sync[h] = s; }
   __syncthreads();
-  if (threadIdx.x == 0) sched_step_body<STAGE>(slot, state, hin, sy, hout);
+  if (threadIdx.x == 0) sched_step_body<STAGE>(slot, state, hin, sy, hout, grps);
 }
 
 // out[slot]: state + per-try sync / rms / shift / symbols (cc:465-475)
@@ -410,7 +435,7 @@ void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t
   const int nslots = B * per_frame;
   prof_scope ps(c, UWSPR_K_SCHED, nslots);
   hipLaunchKernelGGL(k_sched_init, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, cands,
-                     npk, cand_stride, B, per_frame, (float)c->p.cf, c->d_state, c->d_hyps);
+                     npk, cand_stride, B, per_frame, (float)c->p.cf, c->d_state, c->d_hyps, c->d_grps);
 }
 
 // hyps of consecutive stages ping-pong between the two halves of d_hyps;
@@ -422,11 +447,11 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots) {
   dev_hyp *hout = (stage & 1) ? half1 : half0;
   dim3 g(nslots);
   switch (stage) {
-    case 1: hipLaunchKernelGGL(k5_fold_step<1>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, nslots); break;
-    case 2: hipLaunchKernelGGL(k5_fold_step<2>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, nslots); break;
-    case 3: hipLaunchKernelGGL(k5_fold_step<3>, g, dim3(128), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, nslots); break;
-    case 4: hipLaunchKernelGGL(k5_fold_step<4>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, nslots); break;
-    default: hipLaunchKernelGGL(k5_fold_step<5>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, nslots); break;
+    case 1: hipLaunchKernelGGL(k5_fold_step<1>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, nslots); break;
+    case 2: hipLaunchKernelGGL(k5_fold_step<2>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, nslots); break;
+    case 3: hipLaunchKernelGGL(k5_fold_step<3>, g, dim3(128), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, nslots); break;
+    case 4: hipLaunchKernelGGL(k5_fold_step<4>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, nslots); break;
+    default: hipLaunchKernelGGL(k5_fold_step<5>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, nslots); break;
   }
 }
 

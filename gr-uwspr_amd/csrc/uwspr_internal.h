@@ -36,6 +36,20 @@ struct dev_hyp {
   int32_t m_type;
 };
 
+// A lag group: up to 8 hypotheses that differ only in their time lag (same
+// frame, frequency, drift model).  They share the per-symbol tone phasors, so
+// K4 advances the phasor recurrence once and correlates all lags against it.
+struct dev_grp {
+  int32_t frame;     // <0: skip
+  int32_t m_type;
+  float f0, drift, slmc;
+  int32_t nvalid;    // lags in use (the kernel is instantiated for NL >= nvalid)
+  int32_t hyp_base;  // hypothesis index of lag[0]; lag[l] is hypothesis hyp_base + l
+  int32_t lag[8];
+  int32_t _pad;
+};
+static_assert(sizeof(dev_grp) == 64, "dev_grp is one 64-byte record");
+
 // per-candidate refinement state kept in HBM between schedule stages
 struct cand_state {
   int32_t frame;       // <0: empty slot
@@ -92,6 +106,7 @@ struct uwspr_ctx {
   int grid_cap; size_t cap_grid_bytes; float *d_syncgrid;  // [B][grid_cap][ntot]
 
   size_t cap_hyps; uwspr::dev_hyp *d_hyps;
+  size_t cap_grps; uwspr::dev_grp *d_grps;
   size_t cap_abi_hyps; uwspr_hyp *d_abi_hyps;
   size_t cap_p; float4 *d_p;                      // [H][162] tone magnitudes
   size_t cap_sync; float *d_sync;                 // [H]
@@ -101,6 +116,7 @@ struct uwspr_ctx {
   // buffers the current call writes (the context's own, or the caller's device memory)
   uwspr_candidate *cur_cands; int32_t *cur_npk; uwspr_demod_out *cur_dout;
   int last_per_frame;
+  bool use_lag_groups;
   size_t cap_slab; uint8_t *d_slab;
 
   int prof_mask;
@@ -117,6 +133,9 @@ void launch_coarse(uwspr_ctx *c, int B);
 void launch_prep_hyps(uwspr_ctx *c, const uwspr_hyp *abi, dev_hyp *out, int H);
 void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int H,
                      float4 *p);
+// lag-group form: G groups, each instantiated for NL in {5, 6, 8} lags
+void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
+                            int NL, int64_t nhyps, float4 *p);
 void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, float *sync,
                  uint8_t *symbols);
 // schedule stages; see k5_schedule.hip

@@ -55,7 +55,8 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     deps.append(os.path.join(_HERE, "..", "include", "uwspr_hip.h"))
-    cmd = [_hipcc()] + HIPFLAGS + ["-shared"] + srcs + ["-o", LIBPATH]
+    extra = os.environ.get("UWSPR_EXTRA_HIPFLAGS", "").split()   # experiments only
+    cmd = [_hipcc()] + HIPFLAGS + extra + ["-shared"] + srcs + ["-o", LIBPATH]
     stamp = LIBPATH + ".cmd"
     same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
     if force or not same_cmd or _stale(LIBPATH, deps):

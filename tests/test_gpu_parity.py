@@ -228,6 +228,23 @@ def test_schedule_matches_oracle(ctx, oracle, frames, vec):
     assert (out[:, 0]["symbols"] == vec["demod_symbols"]).all()
 
 
+def test_schedule_without_lag_groups_is_identical(G, frames, vec, monkeypatch):
+    """The schedule's lag sweeps run through k4_group (shared tone phasors) by
+    default and through k4_tonecorr with UWSPR_K4_GROUPS=0: byte-identical output."""
+    cands = [vec["cands"][b, :int(vec["npk"][b])] for b in range(4)]
+    per = max(len(c) for c in cands)
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("UWSPR_K4_GROUPS", flag)
+        c = G.Context()
+        try:
+            outs.append(c.demod_batch(frames, cands, max_per_frame=per))
+        finally:
+            c.close()
+    assert outs[0].tobytes() == outs[1].tobytes()
+    assert (outs[0][:, 0]["symbols"] == vec["demod_symbols"]).all()
+
+
 def test_pipeline_device_pointers_equal_host_pointers(ctx, G, frames):
     """The same batch through UWSPR_DEVICE pointers (HBM-resident, what bench.py times)."""
     import torch
