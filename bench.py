@@ -201,38 +201,53 @@ def main():
 
     # ---- configs[2]: the (freq, lag, drift) sweep, N=1 only -----------------
     if rank == 0 and world == 1 and not args.no_sweep:
+        from gr_uwspr_amd import sweep as SW
         Bs = args.sweep_frames
         del frames
         torch.cuda.empty_cache()
         fr2 = G.synth.make_frames_torch(Bs, dev, seed=99, snr_db=args.snr)
-        hy = G.sweep_grid_uniform(Bs, f_c=0.0, shift_c=368)
-        H = hy.size
-        hy_t = torch.from_numpy(np.frombuffer(hy.tobytes(), np.uint8).copy()).to(dev)
+        H = Bs * 200
+        cent = np.zeros(Bs, N.CAND_DTYPE)
+        cent["freq"] = 0.0
+        cent["shift"] = 368
+        cent_t = torch.from_numpy(np.frombuffer(cent.tobytes(), np.uint8).copy()).to(dev)
+        df = np.array(SW.DF_STEPS, np.float32) * np.float32(0.25)
+        dd = np.array(SW.DRIFTS, np.float32)
+        dl = np.array(SW.LAGS, np.int32)
         sync_t = torch.empty(H, dtype=torch.float32, device=dev)
         sym_t = torch.empty(H * 162, dtype=torch.uint8, device=dev)
-        ctx.sync_sweep_into(fr2, hy_t, H, sync_t, sym_t)
-        torch.cuda.synchronize()
-        ctx.prof_enable(True)
-        ctx.prof_read()
-        reps = 3
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            ctx.sync_sweep_into(fr2, hy_t, H, sync_t, sym_t)
-        torch.cuda.synchronize()
-        dts = (time.perf_counter() - t0) / reps
-        p2 = ctx.prof_read()
-        ctx.prof_enable(False)
-        k4ms = p2["tonecorr"]["ms"] / reps
-        result["sweep"] = {
-            "workload": "BASELINE configs[2]: %d frames x 200 (freq,lag,drift) hypotheses, sync + 162 soft symbols each" % Bs,
-            "hypotheses": H, "ms_total": 1e3 * dts, "k4_ms": k4ms,
-            "k5_ms": p2["fold"]["ms"] / reps,
-            "hyps_per_s": H / dts,
-            "algorithmic_GBs_k4": H * HYP_BYTES / (k4ms * 1e-3) / 1e9,
-            "frac_of_hbm_peak_k4": H * HYP_BYTES / (k4ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "fp32_tops_k4": H * HYP_FLOP / (k4ms * 1e-3) / 1e12,
-            "north_star_bar_ms": 28.3,
-        }
+        sweep = {"workload": "BASELINE configs[2]: %d frames x 200 (freq,drift,lag) hypotheses, sync + 162 "
+                             "soft symbols each" % Bs, "hypotheses": H, "north_star_bar_ms": 28.3}
+
+        def timed(fn, reps=3):
+            fn()
+            torch.cuda.synchronize()
+            ctx.prof_enable(True)
+            ctx.prof_read()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - t0) / reps
+            p2 = ctx.prof_read()
+            ctx.prof_enable(False)
+            k4ms = p2["tonecorr"]["ms"] / reps
+            return {"ms_total": 1e3 * dts, "k4_ms": k4ms, "k5_ms": p2["fold"]["ms"] / reps,
+                    "k4_launches": p2["tonecorr"]["launches"] / reps, "hyps_per_s": H / dts,
+                    "algorithmic_GBs_k4": H * HYP_BYTES / (k4ms * 1e-3) / 1e9,
+                    "frac_of_hbm_peak_k4": H * HYP_BYTES / (k4ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+        # grid form (uwspr_sync_grid): shared symbol windows + shared tone phasors
+        sweep["grid"] = timed(lambda: ctx.sync_grid(fr2, cent_t, df, dd, dl, into=(sync_t, sym_t)))
+        grid_sync = sync_t.clone()
+        # flat form (uwspr_sync_sweep) on the same 204800 hypotheses, same order
+        hy = G.sweep_grid_uniform(Bs, f_c=0.0, shift_c=368)
+        hy = hy.reshape(Bs, 5, 8, 5).transpose(0, 1, 3, 2).reshape(-1).copy()
+        hy_t = torch.from_numpy(np.frombuffer(hy.tobytes(), np.uint8).copy()).to(dev)
+        sweep["flat"] = timed(lambda: ctx.sync_sweep_into(fr2, hy_t, H, sync_t, sym_t))
+        sweep["flat"]["fp32_tops_k4"] = H * HYP_FLOP / (sweep["flat"]["k4_ms"] * 1e-3) / 1e12
+        sweep["grid_equals_flat_bitwise"] = bool(torch.equal(grid_sync, sync_t))
+        result["sweep"] = sweep
 
     if rank == 0:
         result["cpu_baseline"] = cpu_baseline(frames_cpu) if frames_cpu is not None else None

@@ -132,6 +132,46 @@ class Context:
                                           C.c_void_p(sym.ctypes.data) if soft else None))
         return sync, sym
 
+    def sync_grid(self, frames, centres, df, ddrift, dlag, soft=True, into=None):
+        """(freq, drift, lag) grid around one centre per frame (uwspr_sync_grid).
+        -> sync [B,nf,ndrift,nlag], symbols [B,nf,ndrift,nlag,162] (numpy), or, with
+        device frames and into=(sync_t, sym_t), results left in those torch tensors."""
+        p, B, where, keep = self._frames(frames)
+        df = np.ascontiguousarray(df, np.float32)
+        ddrift = np.ascontiguousarray(ddrift, np.float32)
+        dlag = np.ascontiguousarray(dlag, np.int32)
+        shape = (B, df.size, ddrift.size, dlag.size)
+        H = int(np.prod(shape))
+        args = (df.size, C.c_void_p(df.ctypes.data), ddrift.size, C.c_void_p(ddrift.ctypes.data),
+                dlag.size, C.c_void_p(dlag.ctypes.data))
+        if where == N.DEVICE:
+            import torch
+            if _is_torch(centres):
+                cent_t = centres
+            else:
+                cent = np.ascontiguousarray(centres, dtype=N.CAND_DTYPE)
+                cent_t = torch.from_numpy(np.frombuffer(cent.tobytes(), np.uint8).copy()).to(frames.device)
+            if into is None:
+                sync_t = torch.empty(H, dtype=torch.float32, device=frames.device)
+                sym_t = torch.empty(H * N.NSYM, dtype=torch.uint8, device=frames.device) if soft else None
+            else:
+                sync_t, sym_t = into
+            self._chk(self.L.uwspr_sync_grid(self.h, p, B, where, C.c_void_p(cent_t.data_ptr()), *args,
+                                             C.c_void_p(sync_t.data_ptr()),
+                                             C.c_void_p(sym_t.data_ptr()) if sym_t is not None else None))
+            if into is not None:
+                return None
+            self.synchronize()
+            return (sync_t.cpu().numpy().reshape(shape),
+                    sym_t.cpu().numpy().reshape(shape + (N.NSYM,)) if soft else None)
+        cent = np.ascontiguousarray(centres, dtype=N.CAND_DTYPE)
+        sync = np.empty(shape, np.float32)
+        sym = np.empty(shape + (N.NSYM,), np.uint8) if soft else None
+        self._chk(self.L.uwspr_sync_grid(self.h, p, B, where, C.c_void_p(cent.ctypes.data), *args,
+                                         C.c_void_p(sync.ctypes.data),
+                                         C.c_void_p(sym.ctypes.data) if soft else None))
+        return sync, sym
+
     def sync_and_demodulate(self, frames, calls):
         """calls: CALL_DTYPE array, one per sync_and_demodulate() invocation
         (sync_and_demodulate_impl.cc:126-131). -> RESULT_DTYPE array."""

@@ -463,6 +463,41 @@ extern "C" int uwspr_sync_sweep(uwspr_ctx *c, const float *frames, int B, const 
   return UWSPR_OK;
 }
 
+extern "C" int uwspr_sync_grid(uwspr_ctx *c, const float *frames, int B, int where,
+                               const uwspr_candidate *centres, int nf, const float *df, int ndrift,
+                               const float *ddrift, int nlag, const int32_t *dlag, float *sync,
+                               uint8_t *symbols) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!centres || !df || !ddrift || !dlag || nf < 1 || ndrift < 1 || nlag < 1 || nf > 32 || ndrift > 32 || nlag > 4096)
+    return fail(c, UWSPR_ERR_ARG, "uwspr_sync_grid: nf=%d ndrift=%d nlag=%d (nf, ndrift <= 32)", nf, ndrift, nlag);
+  const float *d;
+  if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
+  const long long H = (long long)B * nf * ndrift * nlag;
+  if (H > (1LL << 27)) return fail(c, UWSPR_ERR_ARG, "uwspr_sync_grid: %lld hypotheses in one call", H);
+  const bool soft = symbols != nullptr;
+  if ((rc = ensure(c, &c->d_hyps, &c->cap_hyps, (size_t)H))) return rc;
+  if ((rc = ensure_sweep(c, (size_t)H, soft))) return rc;
+  // centres and the lag offsets on the device
+  size_t need_abi = ((size_t)B * sizeof(uwspr_candidate) + (size_t)nlag * sizeof(int32_t) + sizeof(uwspr_hyp) - 1) / sizeof(uwspr_hyp) + 1;
+  if ((rc = ensure(c, &c->d_abi_hyps, &c->cap_abi_hyps, need_abi))) return rc;
+  uwspr_candidate *dcent = reinterpret_cast<uwspr_candidate *>(c->d_abi_hyps);
+  int32_t *ddl = reinterpret_cast<int32_t *>(dcent + B);
+  HIPCHK(c, hipMemcpyAsync(dcent, centres, (size_t)B * sizeof(uwspr_candidate),
+                           where == UWSPR_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(ddl, dlag, (size_t)nlag * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+  if (!launch_tonecorr_grid(c, d, B, dcent, nf, df, ndrift, ddrift, nlag, dlag, ddl, c->d_hyps, c->d_p)) {
+    // window scheme does not fit (huge lag span): the flat kernel on the same hypothesis list
+    launch_tonecorr(c, d, B, c->d_hyps, (int)H, c->d_p);
+  }
+  launch_fold(c, c->d_hyps, c->d_p, (int)H, c->d_sync, soft ? c->d_sym : nullptr);
+  HIPCHK(c, hipGetLastError());
+  if ((rc = copy_out(c, sync, c->d_sync, (size_t)H * 4, where))) return rc;
+  if (soft && (rc = copy_out(c, symbols, c->d_sym, (size_t)H * UWSPR_NSYM, where))) return rc;
+  if (where == UWSPR_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWSPR_OK;
+}
+
 extern "C" int uwspr_sync_and_demodulate_batch(uwspr_ctx *c, const float *frames, int B, int where,
                                                const uwspr_sync_call *calls, int ncalls,
                                                uwspr_sync_result *results) {

@@ -136,6 +136,10 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
 // lag-group form: G groups, each instantiated for NL in {5, 6, 8} lags
 void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
                             int NL, int64_t nhyps, float4 *p);
+// grid form (one centre per frame, shared sample windows); false = does not fit, use the flat path
+bool launch_tonecorr_grid(uwspr_ctx *c, const float *frames, int B, const uwspr_candidate *centres,
+                          int nf, const float *df, int ndrift, const float *ddrift, int nlag,
+                          const int *dlag_host, const int *dlag_dev, dev_hyp *hyps, float4 *p);
 void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, float *sync,
                  uint8_t *symbols);
 // schedule stages; see k5_schedule.hip

@@ -127,7 +127,7 @@ ABI_SYMBOLS = [
     "uwspr_ctx_create", "uwspr_ctx_destroy", "uwspr_last_error", "uwspr_status_string",
     "uwspr_get_info", "uwspr_set_stream", "uwspr_synchronize", "uwspr_fdr_batch",
     "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
-    "uwspr_sync_sweep", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
+    "uwspr_sync_sweep", "uwspr_sync_grid", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
     "uwspr_pipeline_batch", "uwspr_pack_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_deinterleave",
     "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_unpack_message",
     "uwspr_c2_read",
@@ -160,6 +160,7 @@ def lib():
     L.uwspr_fdr_keep_syncgrid.argtypes = [vp, ip]
     L.uwspr_fdr_read_syncgrid.argtypes = [vp, ip, vp]
     L.uwspr_sync_sweep.argtypes = [vp, vp, ip, vp, ip, ip, vp, vp]
+    L.uwspr_sync_grid.argtypes = [vp, vp, ip, ip, vp, ip, vp, ip, vp, ip, vp, vp, vp]
     L.uwspr_sync_and_demodulate_batch.argtypes = [vp, vp, ip, ip, vp, ip, vp]
     L.uwspr_demod_batch.argtypes = [vp, vp, ip, ip, vp, vp, ip, ip, vp]
     L.uwspr_pipeline_batch.argtypes = [vp, vp, ip, ip, ip, vp, vp, vp]

@@ -168,6 +168,22 @@ int uwspr_sync_sweep(uwspr_ctx *ctx, const float *frames, int B,
                      const uwspr_hyp *hyps, int H, int where, float *sync,
                      uint8_t *symbols);
 
+/* The (freq, drift, lag) grid sweep of BASELINE configs[2].  Every frame b has a
+ * centre (a candidate record: freq, shift, m_type and its drift / SLM parameters)
+ * and the same offsets are applied around every centre:
+ *     f0    = centre.freq  + df[i]            (binary32 add, as cc:164 forms f0)
+ *     drift = centre.m_linear.drift + ddrift[j]   (binary32 add; linear centres only)
+ *     lag   = centre.shift + dlag[k]
+ * One grid point = one hypothesis of uwspr_sync_sweep (same arithmetic, bit-identical
+ * results); the grid form lets the kernel keep each symbol window on chip for all
+ * of a frame's points and share the tone phasors between points that differ only in
+ * lag.  df/ddrift/dlag are host arrays (nf, ndrift <= 32); centres [B], sync
+ * [B][nf][ndrift][nlag], symbols [B][nf][ndrift][nlag][162] (or NULL) per `where`. */
+int uwspr_sync_grid(uwspr_ctx *ctx, const float *frames, int B, int where,
+                    const uwspr_candidate *centres, int nf, const float *df, int ndrift,
+                    const float *ddrift, int nlag, const int32_t *dlag, float *sync,
+                    uint8_t *symbols);
+
 /* Argument-for-argument batch form of sync_and_demodulate() (cc:126-131):
  * one call = one invocation of the reference function; results are what it
  * writes back through sync/shift1/f1 (and symbols in mode 2).  Host pointers

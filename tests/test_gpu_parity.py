@@ -151,6 +151,53 @@ def test_sync_sweep_config3_grid(ctx, G, oracle, frames, vec):
         assert (y == sym[q]).all() and np.float32(s).tobytes() == sync[q].tobytes()
 
 
+def test_sync_grid_equals_flat_sweep(ctx, G, oracle, frames, vec):
+    """uwspr_sync_grid (shared windows + shared phasors) is bit-identical to the
+    flat uwspr_sync_sweep on the expanded hypothesis list: config-3 grid shape,
+    a nonlinear centre, an edge-of-frame centre, odd sizes and a > 8 lag list."""
+    N = G.native
+    cents = np.zeros(4, N.CAND_DTYPE)
+    cents[:] = vec["cands"][:, 0]
+    cents[2]["m_type"] = 1; cents[2]["V1"] = -1.0; cents[2]["V2"] = 2.0; cents[2]["p1"] = 0; cents[2]["p2"] = 450
+    cents[3]["shift"] = 40          # lags reach before sample 0 -> cc:205 skipping
+    cases = [
+        (np.arange(-2, 3) * np.float32(0.25), np.array([-1, -0.5, 0, 0.5, 1], np.float32),
+         np.array([-96, -64, -32, 0, 32, 64, 96, 128], np.int32)),                   # configs[2]
+        (np.array([0.0, 0.05, -0.05], np.float32), np.array([0.0], np.float32),
+         np.array([0, -8, 8, -16, 16, -24, 24, -32, 32, -40, 40], np.int32)),        # 11 lags: two blocks
+        (np.array([0.1], np.float32), np.array([0.0, 0.5], np.float32), np.array([5], np.int32)),
+        (np.arange(7, dtype=np.float32) * np.float32(0.125), np.array([0.25], np.float32),
+         np.array([3600, 3400, 100], np.int32)),                                     # runs past the frame end
+    ]
+    for df, dd, dl in cases:
+        sync, sym = ctx.sync_grid(frames, cents, df, dd, dl, soft=True)
+        hy = np.zeros(sync.size, N.HYP_DTYPE)
+        q = 0
+        for b in range(4):
+            for i in range(df.size):
+                for j in range(dd.size):
+                    for k in range(dl.size):
+                        h = hy[q]
+                        h["frame"] = b; h["m_type"] = cents[b]["m_type"]
+                        h["f0"] = np.float32(cents[b]["freq"]) + np.float32(df[i])
+                        lin = np.frombuffer(cents[b].tobytes()[24:28], np.float32)[0]
+                        h["drift"] = np.float32(lin) + np.float32(dd[j]) if cents[b]["m_type"] == 0 else 0.0
+                        h["lag"] = int(cents[b]["shift"]) + int(dl[k])
+                        for key in ("V1", "V2", "p1", "p2"):
+                            h[key] = cents[b][key] if cents[b]["m_type"] == 1 else 0
+                        q += 1
+        fsync, fsym = ctx.sync_sweep(frames, hy, soft=True)
+        assert sync.reshape(-1).tobytes() == fsync.tobytes()
+        assert (sym.reshape(-1, 162) == fsym).all()
+    # and against the committed oracle vectors for the configs[2] grid of frames 0,1
+    df, dd, dl = cases[0]
+    sync, sym = ctx.sync_grid(frames[:2], vec["cands"][:2, 0], df, dd, dl, soft=True)
+    order = vec["sweep_hyps"]   # generated f-outer, lag, drift-inner: reorder to [f][drift][lag]
+    idx = np.arange(400).reshape(2, 5, 8, 5).transpose(0, 1, 3, 2).reshape(-1)
+    assert (sym.reshape(-1, 162) == vec["sweep_symbols"][idx]).all()
+    assert sync.reshape(-1).tobytes() == vec["sweep_sync"][idx].tobytes()
+
+
 def test_sync_sweep_edges(ctx, G, oracle, frames):
     """lags that run off either end of the frame (n<=0 and n>=np are skipped,
     cc:205), nonlinear hypotheses, skipped (frame<0) entries, odd batch sizes."""
