@@ -96,11 +96,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    local = min(local, torch.cuda.device_count() - 1)   # rehearsal: several ranks on one GPU (gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("UWSPR_BENCH_FORCE_PG"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = os.environ.get("UWSPR_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     B = args.frames
     frames = G.synth.make_frames_torch(B, dev, seed=0xC0FFEE + 7919 * rank, snr_db=args.snr)
@@ -146,7 +152,8 @@ def main():
     prof["tonecorr"] = prof_k4["tonecorr"]
     ctx.prof_enable(False)
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64,
+                          device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -162,7 +169,18 @@ def main():
     for b in range(min(B, 64)):
         decoded += 1 if G.decode_candidate(out[b, 0]) is not None else 0
 
-    frames_cpu = frames.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu) else None
+    frames_cpu = frames.cpu().numpy() if (rank == 0 and world == 1) else None
+    # the same batch handed over as HOST buffers (what a GNU Radio block would do):
+    # pageable H2D of the frames + D2H of every result, PCIe inclusive; never `value`
+    host_rate = None
+    if frames_cpu is not None:
+        ctx.pipeline_batch(frames_cpu, max_per_frame=1)
+        t2 = time.perf_counter()
+        for _ in range(3):
+            ctx.pipeline_batch(frames_cpu, max_per_frame=1)
+        host_rate = 3 * B / (time.perf_counter() - t2)
+    if args.no_cpu:
+        frames_cpu = None
     result = None
     if rank == 0:
         k4 = prof["tonecorr"]
@@ -196,6 +214,7 @@ def main():
                          "fp32_tops": fine_hyps * HYP_FLOP * args.steps / (k4["ms"] * 1e-3) / 1e12 if k4["ms"] > 0 else 0.0,
                          "fp32_nofma_peak_tops": FP32_NOFMA_PEAK_TOPS},
             "kernels": kern,
+            "host_pointer_frames_per_s_pcie_inclusive": host_rate,
             "ms_per_step_with_events_on_every_kernel": 1e3 * dt_all_events / args.steps,
         }
 
@@ -252,7 +271,7 @@ def main():
     if rank == 0:
         result["cpu_baseline"] = cpu_baseline(frames_cpu) if frames_cpu is not None else None
         print(json.dumps(result))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

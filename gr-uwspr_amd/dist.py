@@ -44,6 +44,8 @@ def gather_slabs(slab, dst=0):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return slab.unsqueeze(0)
     world = dist.get_world_size()
+    if dist.get_backend() == "gloo" and slab.is_cuda:
+        slab = slab.cpu()          # CPU rehearsal of the N>1 path; RCCL gathers device memory
     if dist.get_rank() == dst:
         out = [torch.empty_like(slab) for _ in range(world)]
         dist.gather(slab, gather_list=out, dst=dst)
