@@ -271,6 +271,17 @@ class Context:
             mask = sum(1 << N.K_NAMES.index(k) for k in which)
         self._chk(self.L.uwspr_prof_enable(self.h, mask))
 
+    def prof_intervals(self, kind, epoch_event_ptr, cap=4096):
+        """(start_ms, stop_ms) arrays of the recorded launches of one family, relative
+        to a caller-recorded hipEvent (e.g. torch.cuda.Event(enable_timing=True).cuda_event)."""
+        a = np.zeros(cap, np.float64)
+        b = np.zeros(cap, np.float64)
+        n = C.c_int(0)
+        self._chk(self.L.uwspr_prof_intervals(self.h, N.K_NAMES.index(kind), C.c_void_p(epoch_event_ptr),
+                                              C.c_void_p(a.ctypes.data), C.c_void_p(b.ctypes.data),
+                                              cap, C.byref(n)))
+        return a[:n.value].copy(), b[:n.value].copy()
+
     def prof_read(self):
         p = N.Prof()
         self._chk(self.L.uwspr_prof_read(self.h, C.byref(p)))

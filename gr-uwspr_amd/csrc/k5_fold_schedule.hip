@@ -7,6 +7,8 @@
 //   soft symbols   cc:216-224 and the mode-2 epilogue cc:240-254
 //   schedule       sync_and_demodulate_impl::demodulate cc:403-482 (S0..S5)
 //   best-of rule   cc:227-231 (strict >, first wins; -1e30 / 0 / 0.0 defaults)
+#include <stdlib.h>
+
 #include "uwspr_internal.h"
 
 #pragma clang fp contract(off)
@@ -168,7 +170,8 @@ void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, floa
                  uint8_t *symbols) {
   if (H <= 0) return;
   prof_scope ps(c, UWSPR_K_FOLD, H);
-  if (H <= 65536) {
+  static const bool lanes_form = getenv("UWSPR_K5_LANES") && atoi(getenv("UWSPR_K5_LANES")) != 0;
+  if (!lanes_form) {
     dim3 g((H + K5W_WAVES - 1) / K5W_WAVES), b(64 * K5W_WAVES);
     if (symbols) hipLaunchKernelGGL(k5_fold_wave<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
     else hipLaunchKernelGGL(k5_fold_wave<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);

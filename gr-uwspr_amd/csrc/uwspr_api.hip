@@ -690,6 +690,26 @@ extern "C" int uwspr_prof_enable(uwspr_ctx *c, int mask) {
   return UWSPR_OK;
 }
 
+extern "C" int uwspr_prof_intervals(uwspr_ctx *c, int kind, void *epoch_event, double *start_ms,
+                                    double *stop_ms, int cap, int *n) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!epoch_event || !start_ms || !stop_ms || !n || cap < 0) return UWSPR_ERR_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int k = 0;
+  for (auto &e : c->prof_events) {
+    if (e.kind != kind) continue;
+    float a = 0.0f, b = 0.0f;
+    if (k < cap && hipEventElapsedTime(&a, (hipEvent_t)epoch_event, e.a) == hipSuccess &&
+        hipEventElapsedTime(&b, (hipEvent_t)epoch_event, e.b) == hipSuccess) {
+      start_ms[k] = a; stop_ms[k] = b;
+      k++;
+    }
+  }
+  *n = k;
+  return UWSPR_OK;
+}
+
 extern "C" int uwspr_prof_read(uwspr_ctx *c, uwspr_prof *o) {
   int rc = ready(c);
   if (rc) return rc;

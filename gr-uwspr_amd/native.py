@@ -128,7 +128,7 @@ ABI_SYMBOLS = [
     "uwspr_get_info", "uwspr_set_stream", "uwspr_synchronize", "uwspr_fdr_batch",
     "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
     "uwspr_sync_sweep", "uwspr_sync_grid", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
-    "uwspr_pipeline_batch", "uwspr_pack_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_deinterleave",
+    "uwspr_pipeline_batch", "uwspr_pack_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
     "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_unpack_message",
     "uwspr_c2_read",
 ]
@@ -167,6 +167,7 @@ def lib():
     L.uwspr_pack_slabs.argtypes = [vp, ip, ip, vp, ip]
     L.uwspr_prof_enable.argtypes = [vp, ip]
     L.uwspr_prof_read.argtypes = [vp, C.POINTER(Prof)]
+    L.uwspr_prof_intervals.argtypes = [vp, ip, vp, vp, vp, ip, C.POINTER(C.c_int)]
     L.uwspr_deinterleave.argtypes = [vp]
     L.uwspr_deinterleave.restype = None
     L.uwspr_fano_decode.argtypes = [vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),

@@ -248,6 +248,12 @@ typedef struct uwspr_prof {
 #define UWSPR_PROF_ALL 0x3f
 int uwspr_prof_enable(uwspr_ctx *ctx, int mask);
 int uwspr_prof_read(uwspr_ctx *ctx, uwspr_prof *out);
+/* Start/stop times (ms after `epoch_event`, a hipEvent_t recorded by the caller
+ * on the same device) of up to `cap` recorded launches of one family, WITHOUT
+ * resetting them; *n receives the count.  Lets a caller that rotates batches over
+ * several contexts/streams account for launches that overlap in time. */
+int uwspr_prof_intervals(uwspr_ctx *ctx, int kind, void *epoch_event, double *start_ms,
+                         double *stop_ms, int cap, int *n);
 
 /* ---- host-side tail of the path ------------------ */
 /* sync_and_demodulate_impl.cc:265-282 */
