@@ -45,6 +45,13 @@ __host__ __device__ inline k3_lds_layout k3_layout(const fdr_consts &f) {
   l.sync = l.uoff + (size_t)UWSPR_NIFR * f.umax * 41 * 4;
   l.umap = l.sync + (size_t)UWSPR_NIFR * UWSPR_NK0 * f.umax * 4;
   l.total = l.umap + (((size_t)UWSPR_NIFR * f.cell_hyps * 2 + 15) & ~(size_t)15);
+  // after the evaluation the tile + offset-table range is reused for the expanded
+  // metrics [ntot rounded to 64] + 3 floats per 64-value slice: grow it if needed
+  const size_t reuse = ((size_t)((f.ntot + 63) & ~63) + 3 * (size_t)((f.ntot + 63) >> 6)) * 4;
+  if (reuse > l.sync) {
+    const size_t extra = (reuse - l.sync + 15) & ~(size_t)15;
+    l.sync += extra; l.umap += extra; l.total += extra;
+  }
   return l;
 }
 
@@ -61,6 +68,9 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
 
   const int tid = threadIdx.x;
   const int nwork = work[0];
+#ifdef K3_STAMPS
+  long long t_a = clock64(), t_b = 0, t_c = 0, t_d = 0;
+#endif
   // persistent workgroups: K2 compacted the (frame, candidate) pairs into a work
   // list, so no workgroup is launched only to find it has no candidate
   for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
@@ -86,6 +96,9 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   for (int idx = tid; idx < UWSPR_NIFR * f.cell_hyps; idx += K3_THREADS)
     umap[idx] = umap_tab[(size_t)r0 * f.cell_hyps + idx];
   __syncthreads();
+#ifdef K3_STAMPS
+  t_b = clock64();
+#endif
 
   // ---- one lane per (cell, distinct offset sequence) -------------------------
   const int nc2 = 2 * f.nc;
@@ -135,6 +148,9 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
     syncbuf[g] = ieee_divf(ss, pw);  // cc:357,390
   }
   __syncthreads();
+#ifdef K3_STAMPS
+  t_c = clock64();
+#endif
 
   const int hc = f.cell_hyps;
   if (syncgrid != nullptr && j < grid_cap) {
@@ -146,25 +162,79 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   }
 
   // ---- replay the running-best selection in reference order ---------------
+  // The rule (cc:360 strict > for linear, cc:392 ratio against the RUNNING best
+  // for nonlinear) is an order-dependent fold over all ntot hypotheses.  It is
+  // replayed exactly, but cheaply:
+  //  (1) all threads expand the metrics into reference order (`full`, reusing the
+  //      tile / offset-table LDS, no longer needed) and reduce every 64-value
+  //      slice to {max over linear, max and min over nonlinear} hypotheses;
+  //  (2) wave 0 scans: 64 slice summaries at a time are tested against the
+  //      current best -- the predicates are monotone in v (v > best; v/best > thr
+  //      rises with v for best > 0 and falls for best < 0), so a slice whose
+  //      extreme value fails cannot contain an acceptance and is skipped -- and
+  //      only slices that may accept are scanned value by value with ballots.
+  float *full = reinterpret_cast<float *>(smem);                       // [ntot]
+  float *ssum = full + ((f.ntot + 63) & ~63);                          // [nslice][3]
+  const int nslice = (f.ntot + 63) >> 6;
+  {
+    const int lane = tid & 63;
+    // thread walks g = tid, tid + 1024, ...: (cell, h) advance by carry, no division in the loop
+    const int qstep = K3_THREADS / hc, rstep = K3_THREADS - qstep * hc;
+    int cell = tid / hc, h = tid - cell * hc;
+    const float ninf = -__builtin_inff(), pinf = __builtin_inff();
+    for (int g = tid; g < nslice * 64; g += K3_THREADS) {
+      const bool in = g < f.ntot;
+      const int ifr_i = cell / UWSPR_NK0;  // constant divisor
+      const float v = in ? syncbuf[cell * f.umax + umap[ifr_i * hc + h]] : 0.0f;
+      const bool lin = h < f.nlin;
+      // NaN never satisfies a predicate: keep it out of the extremes
+      const bool use = in && (v == v);
+      float mlin = (use && lin) ? v : ninf;
+      float mxnl = (use && !lin) ? v : ninf;
+      float mnnl = (use && !lin) ? v : pinf;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        mlin = fmaxf(mlin, __shfl_xor(mlin, o));
+        mxnl = fmaxf(mxnl, __shfl_xor(mxnl, o));
+        mnnl = fminf(mnnl, __shfl_xor(mnnl, o));
+      }
+      if (in) full[g] = v;
+      const int sl = g >> 6;
+      if (lane == 0) { ssum[3 * sl] = mlin; ssum[3 * sl + 1] = mxnl; ssum[3 * sl + 2] = mnnl; }
+      cell += qstep; h += rstep;
+      if (h >= hc) { h -= hc; cell += 1; }
+    }
+  }
+  __syncthreads();
+#ifdef K3_STAMPS
+  long long t_c2 = clock64();
+#endif
   if (tid < 64) {
     float best = -1e30f;
     int gbest = -1;
-    const int ncell = UWSPR_NIFR * UWSPR_NK0;
-    const int nper = (hc + 63) / 64;  // 64-lane slices per cell
-    // value of hypothesis h of a cell (expanded through the sequence map); the
-    // next slice is fetched while the current one is scanned
-    auto fetch = [&](int sl) -> float {
-      const int cell = sl / nper, h = (sl - cell * nper) * 64 + tid;
-      if (cell >= ncell || h >= hc) return 0.0f;
-      return syncbuf[cell * f.umax + umap[(cell / UWSPR_NK0) * hc + h]];
-    };
-    float vnext = fetch(0);
-    for (int sl = 0; sl < ncell * nper; sl++) {
-      const float v = vnext;
-      vnext = fetch(sl + 1);
-      const int cell = sl / nper, h = (sl - cell * nper) * 64 + tid;
-      const bool in = h < hc;
-      const bool lin = h < f.nlin;
+    int pos = 0;  // first slice not yet decided
+    while (pos < nslice) {
+      // find the first slice >= pos that may contain an acceptance
+      int hit = -1;
+      for (int blk = pos & ~63; blk < nslice && hit < 0; blk += 64) {
+        const int sl = blk + tid;
+        bool may = false;
+        if (sl >= pos && sl < nslice) {
+          const float mlin = ssum[3 * sl], mxnl = ssum[3 * sl + 1], mnnl = ssum[3 * sl + 2];
+          may = mlin > best;
+          if (best > 0.0f) may = may || (ieee_divf(mxnl, best) > f.threshold);
+          else if (best < 0.0f) may = may || (ieee_divf(mnnl, best) > f.threshold);
+          else may = true;  // best == +-0: scan exactly
+        }
+        const unsigned long long m = __ballot(may);
+        if (m != 0ull) hit = blk + __ffsll((long long)m) - 1;
+      }
+      if (hit < 0) break;
+      // exact scan of slice `hit`
+      const int g = hit * 64 + tid;
+      const bool in = g < f.ntot;
+      const float v = in ? full[g] : 0.0f;
+      const bool lin = in && (g % hc) < f.nlin;
       int start = 0;
       for (;;) {
         const bool pred = in && tid >= start &&
@@ -173,9 +243,10 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
         if (mask == 0ull) break;
         const int first = __ffsll((long long)mask) - 1;
         best = __shfl(v, first);
-        gbest = cell * hc + (sl - cell * nper) * 64 + first;
+        gbest = hit * 64 + first;
         start = first + 1;
       }
+      pos = hit + 1;
     }
     if (tid == 0) {
       cand->sync = best;
@@ -201,6 +272,10 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
     }
   }
   __syncthreads();  // LDS is reused by the next work item
+#ifdef K3_STAMPS
+  t_d = clock64();
+  if (tid == 0 && blockIdx.x == 7) printf("K3 stamps (cycles): stage %lld eval %lld expand %lld fold %lld\n", t_b - t_a, t_c - t_b, t_c2 - t_c, t_d - t_c2);
+#endif
   }
 }
 
