@@ -69,6 +69,23 @@ class Context:
     def synchronize(self):
         self._chk(self.L.uwspr_synchronize(self.h))
 
+    # -- front-end ---------------------------------------------------------
+    def frontend(self, audio):
+        """12 kS/s real audio [B, nin] -> frames [B, fl, 2] at 375 S/s (uwspr_frontend_batch)."""
+        if _is_torch(audio):
+            import torch
+            B, nin = audio.shape
+            out = torch.empty((B, self.fl, 2), dtype=torch.float32, device=audio.device)
+            self._chk(self.L.uwspr_frontend_batch(self.h, C.c_void_p(audio.data_ptr()), B, nin, N.DEVICE,
+                                                  C.c_void_p(out.data_ptr())))
+            return out
+        a = np.ascontiguousarray(audio, dtype=np.float32)
+        a = a.reshape(1, -1) if a.ndim == 1 else a
+        out = np.empty((a.shape[0], self.fl, 2), np.float32)
+        self._chk(self.L.uwspr_frontend_batch(self.h, C.c_void_p(a.ctypes.data), a.shape[0], a.shape[1],
+                                              N.HOST, C.c_void_p(out.ctypes.data)))
+        return out
+
     # -- FDR ---------------------------------------------------------------
     def fdr_batch(self, frames):
         """-> list (per frame) of candidate record arrays, FDR_impl.cc:214-456."""
@@ -328,6 +345,14 @@ def unpack_message(message7):
     buf = C.create_string_buffer(32)
     rc = N.lib().uwspr_unpack_message(C.c_void_p(m.ctypes.data), buf, 32)
     return rc, buf.value.decode("ascii", "replace")
+
+
+def frontend_taps():
+    """Complex taps g[k] = h[k]*exp(-j*pi*(D-k)/4) of the K0 front-end (float32)."""
+    n = N.lib().uwspr_frontend_taps(None, 0)
+    g = np.zeros((n, 2), np.float32)
+    N.lib().uwspr_frontend_taps(C.c_void_p(g.ctypes.data), n)
+    return g[:, 0] + 1j * g[:, 1]
 
 
 def c2_read(path):

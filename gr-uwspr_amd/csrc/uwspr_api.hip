@@ -91,6 +91,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->device = device;
   c->own_stream = c->stream = nullptr;
   c->d_window = c->d_twiddle = nullptr; c->d_off = nullptr; c->d_umap = nullptr;
+  c->d_fe_taps = nullptr; c->cap_audio = 0; c->d_audio = nullptr;
   c->cap_frames_bytes = 0; c->d_frames = nullptr; c->cap_B = 0;
   c->d_ps = c->d_psavg = c->d_smraw = c->d_smspec = c->d_noise = nullptr;
   c->d_cands = nullptr; c->d_npk = nullptr; c->d_work = nullptr; c->last_B = 0; c->num_cus = 256;
@@ -249,7 +250,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
 extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   if (!c) return;
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
-  void *bufs[] = {c->d_window, c->d_twiddle, c->d_off, c->d_umap, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
+  void *bufs[] = {c->d_window, c->d_twiddle, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
                   c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps,
                   c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab};
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -329,6 +330,50 @@ static int copy_out(uwspr_ctx *c, void *dst, const void *src, size_t bytes, int 
   if (!dst || bytes == 0) return UWSPR_OK;
   HIPCHK(c, hipMemcpyAsync(dst, src, bytes, where == UWSPR_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
   return UWSPR_OK;
+}
+
+// -------------------------------------------------------------- front-end
+extern "C" int uwspr_frontend_batch(uwspr_ctx *c, const float *audio, int B, int nin, int where,
+                                    float *frames_out) {
+  int rc = ready(c);
+  if (rc) return rc;
+  const int nout = c->fc.fl;
+  if (!audio || !frames_out || B <= 0 || nin <= 0) return fail(c, UWSPR_ERR_ARG, "uwspr_frontend_batch: audio/out/B/nin");
+  if (c->p.fs != 375) return fail(c, UWSPR_ERR_UNSUPPORTED, "front-end is 12000 -> 375 S/s (fs=%d)", c->p.fs);
+  if (!c->d_fe_taps) {
+    std::vector<float> g;
+    frontend_taps(g);
+    HIPCHK(c, hipMalloc((void **)&c->d_fe_taps, g.size() * sizeof(float)));
+    HIPCHK(c, hipMemcpy(c->d_fe_taps, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
+  const float *da = audio;
+  float *dout = frames_out;
+  if (where == UWSPR_HOST) {
+    if ((rc = ensure(c, &c->d_audio, &c->cap_audio, (size_t)B * nin))) return rc;
+    size_t cap = c->cap_frames_bytes / sizeof(float);
+    rc = ensure(c, &c->d_frames, &cap, (size_t)B * nout * 2);
+    c->cap_frames_bytes = cap * sizeof(float);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_audio, audio, (size_t)B * nin * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    da = c->d_audio; dout = c->d_frames;
+  } else if (where != UWSPR_DEVICE) {
+    return fail(c, UWSPR_ERR_ARG, "where=%d", where);
+  }
+  launch_frontend(c, da, B, nin, (float2 *)dout, nout);
+  HIPCHK(c, hipGetLastError());
+  if (where == UWSPR_HOST) {
+    HIPCHK(c, hipMemcpyAsync(frames_out, c->d_frames, (size_t)B * nout * 2 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_frontend_taps(float *taps_re_im, int cap_pairs) {
+  std::vector<float> g;
+  frontend_taps(g);
+  const int n = (int)g.size() / 2;
+  if (taps_re_im) for (int i = 0; i < 2 * std::min(n, cap_pairs); i++) taps_re_im[i] = g[i];
+  return n;
 }
 
 // -------------------------------------------------------------------- FDR

@@ -90,6 +90,8 @@ struct uwspr_ctx {
   float *d_twiddle;    // [256][2]
   uint32_t *d_off;     // [n_ifr][umax][41]: distinct offset sequences, 4 x int8 (ifd-ifr) per word
   uint16_t *d_umap;    // [n_ifr][cell_hyps]: hypothesis -> distinct sequence
+  float *d_fe_taps;    // [1025][2] complex front-end taps (K0), built on first use
+  size_t cap_audio; float *d_audio;   // staging when the audio is host memory
 
   // batch scratch (grown on demand, never shrunk)
   size_t cap_frames_bytes; float *d_frames;       // staging when frames are host memory
@@ -127,6 +129,8 @@ struct uwspr_ctx {
 namespace uwspr {
 
 // ---- launchers (each enqueues on ctx->stream) ------------------------------
+void frontend_taps(std::vector<float> &g);
+void launch_frontend(uwspr_ctx *c, const float *audio, int B, int nin, float2 *out, int nout);
 void launch_spectrogram(uwspr_ctx *c, const float *frames, int B);
 void launch_spectrum(uwspr_ctx *c, int B);
 void launch_coarse(uwspr_ctx *c, int B);

@@ -18,7 +18,7 @@ LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libuwspr_hip.so")
 HOSTLIB = os.path.join(LIBDIR, "libuwspr_blocks.so")
 
-SOURCES = ["uwspr_api.hip", "k1_spectrogram.hip", "k2_spectrum.hip", "k3_coarse.hip",
+SOURCES = ["uwspr_api.hip", "k0_frontend.hip", "k1_spectrogram.hip", "k2_spectrum.hip", "k3_coarse.hip",
            "k4_tonecorr.hip", "k5_fold_schedule.hip", "host_tail.cpp"]
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
             "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-Wall", "-Wno-unused-function"]
@@ -125,7 +125,8 @@ class Prof(C.Structure):
 # every symbol include/uwspr_hip.h declares
 ABI_SYMBOLS = [
     "uwspr_ctx_create", "uwspr_ctx_destroy", "uwspr_last_error", "uwspr_status_string",
-    "uwspr_get_info", "uwspr_set_stream", "uwspr_synchronize", "uwspr_fdr_batch",
+    "uwspr_get_info", "uwspr_set_stream", "uwspr_synchronize", "uwspr_frontend_batch",
+    "uwspr_frontend_taps", "uwspr_fdr_batch",
     "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
     "uwspr_sync_sweep", "uwspr_sync_grid", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
     "uwspr_pipeline_batch", "uwspr_pack_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
@@ -155,6 +156,8 @@ def lib():
     L.uwspr_get_info.argtypes = [vp, C.POINTER(Info)]
     L.uwspr_set_stream.argtypes = [vp, vp]
     L.uwspr_synchronize.argtypes = [vp]
+    L.uwspr_frontend_batch.argtypes = [vp, vp, ip, ip, ip, vp]
+    L.uwspr_frontend_taps.argtypes = [vp, ip]
     L.uwspr_fdr_batch.argtypes = [vp, vp, ip, ip, vp, vp]
     L.uwspr_fdr_read_spectrum.argtypes = [vp, ip, vp, vp, vp, vp, vp]
     L.uwspr_fdr_keep_syncgrid.argtypes = [vp, ip]

@@ -124,3 +124,30 @@ def make_frames_torch(B, device, seed=0xC0FFEE, snr_db=-20.0, halfbandwidth=10, 
             out[s:e] += sigma * torch.randn((e - s, FL, 2), generator=g, device=device,
                                             dtype=torch.float32)
     return out
+
+
+def make_audio(B, seed=0xA0D10, snr_db=-15.0, f_off=None, rate=12000, carrier=1500.0):
+    """Real 12 kS/s audio records (B x 1.44 M samples) carrying one WSPR transmission
+    each at `carrier` + offset Hz: input for the K0 front-end.
+    Symbol length 8192 samples (256 at 375 S/s), start at sample 375*32."""
+    nin = FL * 32
+    out = np.zeros((B, nin), np.float32)
+    meta = []
+    spb = SPB * 32
+    for b in range(B):
+        rng = np.random.Generator(np.random.Philox(seed + b))
+        bits = rng.integers(0, 2, size=(1, 50))
+        sym = encode_messages(bits)[0].astype(np.float64)
+        fo = rng.uniform(-4, 4) if f_off is None else f_off
+        ftone = np.repeat((sym - 1.5) * FS / SPB, spb) + fo + carrier
+        phase = 2.0 * np.pi * np.cumsum(ftone) / rate
+        sig = np.zeros(nin)
+        s0 = START * 32
+        sig[s0:s0 + NSYM * spb] = np.cos(phase)
+        # complex baseband amplitude after the mixer is 1/2: sigma for SNR in 2500 Hz
+        if snr_db is not None:
+            sigma = 0.5 * np.sqrt(10.0 ** (-(snr_db) / 10.0) * (rate / 2.0) / 2500.0) * np.sqrt(2.0)
+            sig += sigma * rng.standard_normal(nin)
+        out[b] = sig.astype(np.float32)
+        meta.append({"bits": bits[0].astype(np.uint8), "f_off": fo})
+    return out, meta

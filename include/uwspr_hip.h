@@ -139,6 +139,18 @@ int uwspr_get_info(const uwspr_ctx *ctx, uwspr_info *info);
 int uwspr_set_stream(uwspr_ctx *ctx, void *hip_stream);
 int uwspr_synchronize(uwspr_ctx *ctx);
 
+/* ---- front-end -------------------------------------- */
+/* 12 kS/s real audio -> fl complex samples at 375 S/s: mix by -1500 Hz, 1025-tap
+ * Hamming low-pass (100 Hz), decimate by 32 -- our own single-stage equivalent of
+ * the GNU Radio filter chain of examples/WaveFilePlusNoiseDecode.grc:840-916,
+ * 1767-1768 (third-party blocks; taps are version-dependent: parity unpinned).
+ * audio [B][nin] (zero beyond the record), frames_out [B][fl] (I,Q) pairs.
+ * uwspr_frontend_taps returns the tap count and copies the complex taps
+ * h[k]*exp(-j*pi*(D-k)/4) so a caller can restate the formula. */
+int uwspr_frontend_batch(uwspr_ctx *ctx, const float *audio, int B, int nin, int where,
+                         float *frames_out);
+int uwspr_frontend_taps(float *taps_re_im, int cap_pairs);
+
 /* ---- coarse search: FDR_impl::transform, FDR_impl.cc:214-456 ------------ */
 /* cands: [B][maxfreqs] records; npk: [B].  Same candidate order, fields and
  * selection rule (running-best, FDR_impl.cc:360,392) as the reference. */
