@@ -447,16 +447,20 @@ constexpr int K4GR_WAVES = 4;
 template <int NL>
 __global__ __launch_bounds__(64 * K4GR_WAVES) void k4_grid(
     const float2 *__restrict__ frames, int fl, int nframes,
-    const uwspr_candidate *__restrict__ centres, grid_args ga, float cf, float *__restrict__ p_out) {
+    const uwspr_candidate *__restrict__ centres, const int32_t *__restrict__ cframe,
+    grid_args ga, float cf, float *__restrict__ p_out) {
   extern __shared__ __align__(16) float lds_dyn[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float2 *win = reinterpret_cast<float2 *>(lds_dyn) + (size_t)wv * ga.wmax * ga.wstride;
 
-  const int b = blockIdx.y;
+  const int b = blockIdx.y;                      // centre index
   const int npairs = UWSPR_NSYM * ga.ncombo;
-  const int q0 = (blockIdx.x * K4GR_WAVES + wv) * 16;
+  const int nwv = blockDim.x >> 6;
+  const int q0 = (blockIdx.x * nwv + wv) * 16;
   if (q0 >= npairs) return;  // wave-uniform
+  const int frame = cframe ? cframe[b] : b;     // several centres may share a frame
+  if (frame < 0 || frame >= nframes) return;    // dead centre: its hypotheses are marked skipped
   const uwspr_candidate ce = centres[b];
   const int i_first = q0 / ga.ncombo;
   const int i_last = min(q0 + 15, npairs - 1) / ga.ncombo;
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(64 * K4GR_WAVES) void k4_grid(
 
   // ---- load the symbol windows (whole) ------------------------------------
   {
-    const float2 *fb = frames + (long long)b * fl;
+    const float2 *fb = frames + (long long)frame * fl;
     const int n0 = ce.shift + ga.dlag_min + 256 * i_first;
     const int tot = nwin * ga.wlen;
     for (int e = lane; e < tot; e += 64) {
@@ -493,6 +497,8 @@ __global__ __launch_bounds__(64 * K4GR_WAVES) void k4_grid(
     if (ce.m_type == UWSPR_LINEAR) {
       const float drift = ce.m_linear.drift + ga.ddrift[di];
       fp = (float)((double)f0 + ((double)drift / 2.0) * ((double)(float)i - 81.0) / 81.0);
+    } else if (ce.m_type == 2) {
+      fp = f0 + ce.m_linear.drift;  // internal: nonlinear centre with its SLM constant precomputed
     } else {
       // slmFrequencyDrift(m_nl, cf, t = 0), lib/slm.cc:36-73
       const double q1 = (double)ce.m_nonlinear.p1, q2 = (double)ce.m_nonlinear.p2;
@@ -567,14 +573,70 @@ __global__ void k_grid_hyps(const uwspr_candidate *__restrict__ centres, grid_ar
 }
 
 template <int NL>
-static void launch_grid_t(uwspr_ctx *c, const float2 *fr, int B, const uwspr_candidate *centres,
-                          const grid_args &ga, float *po) {
+static void launch_grid_t(uwspr_ctx *c, const float2 *fr, int nframes, int ncentres,
+                          const uwspr_candidate *centres, const int32_t *cframe, const grid_args &ga,
+                          int wpw, float *po) {
   const int npairs = UWSPR_NSYM * ga.ncombo;
   const int waves = (npairs + 15) / 16;
-  dim3 grid((waves + K4GR_WAVES - 1) / K4GR_WAVES, B);
-  const size_t lds = (size_t)K4GR_WAVES * ga.wmax * ga.wstride * sizeof(float2);
-  hipLaunchKernelGGL(k4_grid<NL>, grid, dim3(64 * K4GR_WAVES), lds, c->stream, fr, c->fc.fl, B, centres,
-                     ga, (float)c->p.cf, po);
+  dim3 grid((waves + wpw - 1) / wpw, ncentres);
+  const size_t lds = (size_t)wpw * ga.wmax * ga.wstride * sizeof(float2);
+  hipLaunchKernelGGL(k4_grid<NL>, grid, dim3(64 * wpw), lds, c->stream, fr, c->fc.fl, nframes, centres,
+                     cframe, ga, (float)c->p.cf, po);
+}
+
+// waves per workgroup such that the symbol windows fit 64 KB of LDS (0 = does not fit)
+static int grid_waves_per_wg(const grid_args &ga) {
+  for (int w = K4GR_WAVES; w >= 1; w >>= 1)
+    if ((size_t)w * ga.wmax * ga.wstride * sizeof(float2) <= 64 * 1024) return w;
+  return 0;
+}
+
+// One lag block (<= 8 lags) of a grid around `ncentres` centres; false = does not fit LDS.
+bool launch_grid_block(uwspr_ctx *c, const float *frames, int nframes, int ncentres,
+                       const uwspr_candidate *centres, const int32_t *cframe, grid_args &ga,
+                       const int *dlag, int nv, int64_t units, float4 *p) {
+  int lo = dlag[0], hi = dlag[0];
+  for (int l = 1; l < nv; l++) { lo = std::min(lo, dlag[l]); hi = std::max(hi, dlag[l]); }
+  ga.nvalid = nv; ga.dlag_min = lo;
+  ga.wlen = 256 + (hi - lo);
+  ga.wstride = ga.wlen | 1;  // odd stride: windows of a wave start on different bank pairs
+  for (int l = 0; l < 8; l++) ga.off[l] = dlag[std::min(l, nv - 1)] - lo;
+  const int wpw = grid_waves_per_wg(ga);
+  if (wpw == 0) return false;
+  prof_scope ps(c, UWSPR_K_TONECORR, units);
+  const float2 *fr = (const float2 *)frames;
+  float *po = (float *)p;
+  const int NL = nv <= 1 ? 1 : nv <= 2 ? 2 : nv <= 4 ? 4 : nv <= 5 ? 5 : nv <= 6 ? 6 : 8;
+  switch (NL) {
+    case 1: launch_grid_t<1>(c, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
+    case 2: launch_grid_t<2>(c, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
+    case 4: launch_grid_t<4>(c, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
+    case 5: launch_grid_t<5>(c, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
+    case 6: launch_grid_t<6>(c, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
+    default: launch_grid_t<8>(c, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
+  }
+  return true;
+}
+
+static void grid_args_init(grid_args &ga, int nf, const float *df, int ndrift, const float *ddrift, int nlag) {
+  memset(&ga, 0, sizeof(ga));
+  ga.nf = nf; ga.ndrift = ndrift; ga.ncombo = nf * ndrift; ga.nlag_total = nlag;
+  for (int i = 0; i < nf; i++) ga.df[i] = df[i];
+  for (int i = 0; i < ndrift; i++) ga.ddrift[i] = ddrift[i];
+  ga.wmax = std::min(16, (15 + ga.ncombo - 1) / ga.ncombo + 1);
+}
+
+// The schedule's frequency / drift stages (S1, S4: 5 frequencies; S2: 2 drifts) around one
+// centre per candidate slot, all at a single lag: one grid block, hypotheses slot*ncombo + q.
+bool launch_tonecorr_stage_grid(uwspr_ctx *c, const float *frames, int nframes, int nslots,
+                                const uwspr_candidate *centres, const int32_t *cframe, int nf,
+                                const float *df, int ndrift, const float *ddrift, float4 *p) {
+  grid_args ga;
+  grid_args_init(ga, nf, df, ndrift, ddrift, 1);
+  const int zero = 0;
+  ga.lag_base = 0;
+  return launch_grid_block(c, frames, nframes, nslots, centres, cframe, ga, &zero, 1,
+                           (int64_t)nslots * nf * ndrift, p);
 }
 
 // returns false when the grid does not fit the on-chip window scheme (caller falls back)
@@ -583,11 +645,7 @@ bool launch_tonecorr_grid(uwspr_ctx *c, const float *frames, int B, const uwspr_
                           const int *dlag_host, const int *dlag_dev, dev_hyp *hyps, float4 *p) {
   if (nf < 1 || nf > 32 || ndrift < 1 || ndrift > 32 || nlag < 1) return false;
   grid_args ga;
-  memset(&ga, 0, sizeof(ga));
-  ga.nf = nf; ga.ndrift = ndrift; ga.ncombo = nf * ndrift; ga.nlag_total = nlag;
-  for (int i = 0; i < nf; i++) ga.df[i] = df[i];
-  for (int i = 0; i < ndrift; i++) ga.ddrift[i] = ddrift[i];
-  ga.wmax = std::min(16, (15 + ga.ncombo - 1) / ga.ncombo + 1);
+  grid_args_init(ga, nf, df, ndrift, ddrift, nlag);
   {
     prof_scope ps(c, UWSPR_K_SCHED, (int64_t)B * ga.ncombo * nlag);
     const long long H = (long long)B * ga.ncombo * nlag;
@@ -597,26 +655,10 @@ bool launch_tonecorr_grid(uwspr_ctx *c, const float *frames, int B, const uwspr_
   // lag blocks of up to 8; each block has its own window span
   for (int base = 0; base < nlag; base += 8) {
     const int nv = std::min(8, nlag - base);
-    int lo = dlag_host[base], hi = dlag_host[base];
-    for (int l = 1; l < nv; l++) { lo = std::min(lo, dlag_host[base + l]); hi = std::max(hi, dlag_host[base + l]); }
-    ga.lag_base = base; ga.nvalid = nv; ga.dlag_min = lo;
-    ga.wlen = 256 + (hi - lo);
-    ga.wstride = ga.wlen | 1;  // odd stride: windows of a wave start on different bank pairs
-    for (int l = 0; l < 8; l++) ga.off[l] = dlag_host[base + std::min(l, nv - 1)] - lo;
-    const size_t lds = (size_t)K4GR_WAVES * ga.wmax * ga.wstride * sizeof(float2);
-    if (lds > 64 * 1024) return false;
-    prof_scope ps(c, UWSPR_K_TONECORR, (int64_t)B * ga.ncombo * nv);
-    const float2 *fr = (const float2 *)frames;
-    float *po = (float *)p;
-    const int NL = nv <= 1 ? 1 : nv <= 2 ? 2 : nv <= 4 ? 4 : nv <= 5 ? 5 : nv <= 6 ? 6 : 8;
-    switch (NL) {
-      case 1: launch_grid_t<1>(c, fr, B, centres, ga, po); break;
-      case 2: launch_grid_t<2>(c, fr, B, centres, ga, po); break;
-      case 4: launch_grid_t<4>(c, fr, B, centres, ga, po); break;
-      case 5: launch_grid_t<5>(c, fr, B, centres, ga, po); break;
-      case 6: launch_grid_t<6>(c, fr, B, centres, ga, po); break;
-      default: launch_grid_t<8>(c, fr, B, centres, ga, po); break;
-    }
+    ga.lag_base = base;
+    if (!launch_grid_block(c, frames, B, B, centres, nullptr, ga, dlag_host + base, nv,
+                           (int64_t)B * ga.ncombo * nv, p))
+      return false;
   }
   return true;
 }

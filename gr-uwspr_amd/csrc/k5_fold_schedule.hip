@@ -233,6 +233,16 @@ __device__ inline void emit_group(dev_grp *g, const cand_state &st, bool on, flo
   for (int l = 0; l < 8; l++) g->lag[l] = l < n ? lags[l] : lags[0];
 }
 
+// the same stage as a grid centre (K4 grid form: one symbol window per candidate and symbol,
+// shared by the stage's frequencies / drifts)
+__device__ inline void emit_centre(uwspr_candidate *ce, int32_t *cframe, const cand_state &st, bool on) {
+  ce->freq = st.f1; ce->snr = 0.0f; ce->drift = 0.0f; ce->sync = 0.0f; ce->shift = st.shift1;
+  ce->m_nonlinear.V1 = 0.0; ce->m_nonlinear.V2 = 0.0; ce->m_nonlinear.p1 = 0; ce->m_nonlinear.p2 = 0;
+  if (st.m_type == UWSPR_LINEAR) { ce->m_type = UWSPR_LINEAR; ce->m_linear.drift = st.drift1; }
+  else { ce->m_type = 2; ce->m_linear.drift = st.slmc; }   // internal: precomputed SLM constant
+  *cframe = on ? st.frame : -1;
+}
+
 // cc:227-231 over a list scanned in order: strict >, defaults -1e30 / 0 / 0.0
 struct best3 { float sync; int shift; float f; };
 __device__ inline best3 best_of(const float *sy, const dev_hyp *hy, int n) {
@@ -285,7 +295,9 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
                                                 const dev_hyp *__restrict__ hin,
                                                 const float *sync_of_slot,
                                                 dev_hyp *__restrict__ hout,
-                                                dev_grp *__restrict__ grps) {
+                                                dev_grp *__restrict__ grps,
+                                                uwspr_candidate *__restrict__ cent,
+                                                int32_t *__restrict__ cframe) {
   cand_state st = state[slot];
   const bool live = st.frame >= 0;
   constexpr int NIN = STAGE == 1 ? 5 : STAGE == 2 ? 5 : STAGE == 3 ? 2 : STAGE == 4 ? 5 : 5;
@@ -299,6 +311,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     if (live) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
     for (int q = 0; q < 5; q++)
       emit(&ho[q], st, live, st.shift1, st.f1 + (float)(q - 2) * 0.25f, st.drift1);
+    emit_centre(&cent[slot], &cframe[slot], st, live);
   } else if (STAGE == 2) {
     // after S1 -> S2 (cc:423-433): linear only, drift1 +- 0.5 at (f1, shift1)
     if (live) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
@@ -308,6 +321,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     const float f0 = st.f1 + (float)0 * 0.0f;
     emit(&ho[0], st, lin, st.shift1, f0, st.driftp);
     emit(&ho[1], st, lin, st.shift1, f0, st.driftm);
+    emit_centre(&cent[slot], &cframe[slot], st, lin);
   } else if (STAGE == 3) {
     // after S2 (cc:434-441), gate (cc:443) -> S3 (cc:444-447): lag = shift1-32..+32 step 16
     if (live && st.m_type == UWSPR_LINEAR) {
@@ -332,6 +346,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     if (st.worth) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
     for (int q = 0; q < 5; q++)
       emit(&ho[q], st, st.worth != 0, st.shift1, st.f1 + (float)(q - 2) * 0.05f, st.drift1);
+    emit_centre(&cent[slot], &cframe[slot], st, st.worth != 0);
   } else {
     // after S4 -> S5 (cc:457-468): 17 jiggered shifts, mode 2
     if (st.worth) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
@@ -356,7 +371,8 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
 template <int STAGE>
 __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__restrict__ hin,
                              const float4 *__restrict__ p, float *__restrict__ sync,
-                             dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps, int nslots) {
+                             dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
+                             uwspr_candidate *__restrict__ cent, int32_t *__restrict__ cframe, int nslots) {
   constexpr int NIN = STAGE == 3 ? 2 : 5;
   __shared__ k5_wave_lds L[NIN];
   __shared__ float sy[NIN];
@@ -366,7 +382,7 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
   const float s = fold_wave<false>(hin, p, h, 50.0f, nullptr, L[wv], nullptr);
   if ((threadIdx.x & 63) == 0) { sy[wv] = s; sync[h] = s; }
   __syncthreads();
-  if (threadIdx.x == 0) sched_step_body<STAGE>(slot, state, hin, sy, hout, grps);
+  if (threadIdx.x == 0) sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe);
 }
 
 // out[slot]: state + per-try sync / rms / shift / symbols (cc:465-475)
@@ -450,11 +466,11 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots) {
   dev_hyp *hout = (stage & 1) ? half1 : half0;
   dim3 g(nslots);
   switch (stage) {
-    case 1: hipLaunchKernelGGL(k5_fold_step<1>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, nslots); break;
-    case 2: hipLaunchKernelGGL(k5_fold_step<2>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, nslots); break;
-    case 3: hipLaunchKernelGGL(k5_fold_step<3>, g, dim3(128), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, nslots); break;
-    case 4: hipLaunchKernelGGL(k5_fold_step<4>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, nslots); break;
-    default: hipLaunchKernelGGL(k5_fold_step<5>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, nslots); break;
+    case 1: hipLaunchKernelGGL(k5_fold_step<1>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots); break;
+    case 2: hipLaunchKernelGGL(k5_fold_step<2>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots); break;
+    case 3: hipLaunchKernelGGL(k5_fold_step<3>, g, dim3(128), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots); break;
+    case 4: hipLaunchKernelGGL(k5_fold_step<4>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots); break;
+    default: hipLaunchKernelGGL(k5_fold_step<5>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots); break;
   }
 }
 

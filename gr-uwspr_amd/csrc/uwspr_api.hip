@@ -96,7 +96,8 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->d_ps = c->d_psavg = c->d_smraw = c->d_smspec = c->d_noise = nullptr;
   c->d_cands = nullptr; c->d_npk = nullptr; c->d_work = nullptr; c->last_B = 0; c->num_cus = 256;
   c->grid_cap = 0; c->cap_grid_bytes = 0; c->d_syncgrid = nullptr;
-  c->cap_hyps = 0; c->d_hyps = nullptr; c->cap_grps = 0; c->d_grps = nullptr; c->cap_abi_hyps = 0; c->d_abi_hyps = nullptr;
+  c->cap_hyps = 0; c->d_hyps = nullptr; c->cap_grps = 0; c->d_grps = nullptr;
+  c->cap_cent = 0; c->d_cent = nullptr; c->d_cent_frame = nullptr; c->cap_abi_hyps = 0; c->d_abi_hyps = nullptr;
   c->cap_p = 0; c->d_p = nullptr; c->cap_sync = 0; c->d_sync = nullptr;
   c->cap_sym = 0; c->d_sym = nullptr; c->cap_state = 0; c->d_state = nullptr;
   c->cap_dout = 0; c->d_dout = nullptr; c->prof_mask = 0;
@@ -104,6 +105,9 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   // lag sweeps of the schedule share their tone phasors (k4_group); UWSPR_K4_GROUPS=0 falls
   // back to one lane-set per hypothesis (k4_tonecorr) -- both are parity-tested
   c->use_lag_groups = !(getenv("UWSPR_K4_GROUPS") && atoi(getenv("UWSPR_K4_GROUPS")) == 0);
+  // frequency/drift stages through the grid form: parity-tested but measured 9 % SLOWER than the
+  // flat kernel at 5 hypotheses per candidate (4 waves/SIMD, window loads not overlapped): opt-in
+  c->use_stage_grid = getenv("UWSPR_K4_STAGE_GRID") && atoi(getenv("UWSPR_K4_STAGE_GRID")) != 0;
   c->cap_slab = 0; c->d_slab = nullptr;
   *out = c;  // handed back even on failure so uwspr_last_error() can be read
 
@@ -251,7 +255,7 @@ extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   if (!c) return;
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
   void *bufs[] = {c->d_window, c->d_twiddle, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
-                  c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps,
+                  c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_cent,
                   c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab};
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (auto &e : c->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -630,6 +634,9 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
   if ((rc = ensure(c, &c->d_state, &c->cap_state, nslots))) return rc;
   if ((rc = ensure(c, &c->d_hyps, &c->cap_hyps, 2 * nslots * UWSPR_NJIG))) return rc;
   if ((rc = ensure(c, &c->d_grps, &c->cap_grps, 3 * nslots))) return rc;
+  // centres (48 B) followed by their frame indices (4 B): 13 int32 per slot in one buffer
+  if ((rc = ensure(c, &c->d_cent, &c->cap_cent, (nslots * 13 + 11) / 12 + 1))) return rc;
+  c->d_cent_frame = reinterpret_cast<int32_t *>(c->d_cent + nslots);
   if ((rc = ensure_sweep(c, nslots * UWSPR_NJIG, true))) return rc;
   if ((rc = ensure(c, &c->d_dout, &c->cap_dout, nslots))) return rc;
   c->cur_dout = user_out ? user_out : c->d_dout;
@@ -640,7 +647,19 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
     const dev_hyp *h = half[s & 1];
     // lag sweeps (S0, S3, the 17 jiggered shifts) share their tone phasors
     const bool use_groups = c->use_lag_groups;
-    if (use_groups && (s == 0 || s == 3)) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)nslots, 5, H, c->d_p);
+    // frequency / drift stages through the grid form (whole symbol windows on chip)
+    static const float df25[5] = {-2.0f * 0.25f, -1.0f * 0.25f, 0.0f * 0.25f, 1.0f * 0.25f, 2.0f * 0.25f};
+    static const float df05[5] = {-2.0f * 0.05f, -1.0f * 0.05f, 0.0f * 0.05f, 1.0f * 0.05f, 2.0f * 0.05f};
+    static const float zero1[1] = {0.0f}, dd2[2] = {0.5f, -0.5f};
+    bool done = false;
+    if (c->use_stage_grid && (s == 1 || s == 4))
+      done = launch_tonecorr_stage_grid(c, dframes, B, (int)nslots, c->d_cent, c->d_cent_frame, 5,
+                                        s == 1 ? df25 : df05, 1, zero1, c->d_p);
+    else if (c->use_stage_grid && s == 2)
+      done = launch_tonecorr_stage_grid(c, dframes, B, (int)nslots, c->d_cent, c->d_cent_frame, 1, zero1,
+                                        2, dd2, c->d_p);
+    if (done) { /* launched */ }
+    else if (use_groups && (s == 0 || s == 3)) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)nslots, 5, H, c->d_p);
     else if (use_groups && s == 5) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, H, c->d_p);
     else launch_tonecorr(c, dframes, B, h, H, c->d_p);
     if (s < 5) {

@@ -109,6 +109,7 @@ struct uwspr_ctx {
 
   size_t cap_hyps; uwspr::dev_hyp *d_hyps;
   size_t cap_grps; uwspr::dev_grp *d_grps;
+  size_t cap_cent; uwspr_candidate *d_cent; int32_t *d_cent_frame;   // per-slot grid centres (S1/S2/S4)
   size_t cap_abi_hyps; uwspr_hyp *d_abi_hyps;
   size_t cap_p; float4 *d_p;                      // [H][162] tone magnitudes
   size_t cap_sync; float *d_sync;                 // [H]
@@ -118,7 +119,7 @@ struct uwspr_ctx {
   // buffers the current call writes (the context's own, or the caller's device memory)
   uwspr_candidate *cur_cands; int32_t *cur_npk; uwspr_demod_out *cur_dout;
   int last_per_frame;
-  bool use_lag_groups;
+  bool use_lag_groups, use_stage_grid;
   size_t cap_slab; uint8_t *d_slab;
 
   int prof_mask;
@@ -144,6 +145,9 @@ void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_
 bool launch_tonecorr_grid(uwspr_ctx *c, const float *frames, int B, const uwspr_candidate *centres,
                           int nf, const float *df, int ndrift, const float *ddrift, int nlag,
                           const int *dlag_host, const int *dlag_dev, dev_hyp *hyps, float4 *p);
+bool launch_tonecorr_stage_grid(uwspr_ctx *c, const float *frames, int nframes, int nslots,
+                                const uwspr_candidate *centres, const int32_t *cframe, int nf,
+                                const float *df, int ndrift, const float *ddrift, float4 *p);
 void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, float *sync,
                  uint8_t *symbols);
 // schedule stages; see k5_schedule.hip

@@ -281,14 +281,16 @@ def test_schedule_without_lag_groups_is_identical(G, frames, vec, monkeypatch):
     cands = [vec["cands"][b, :int(vec["npk"][b])] for b in range(4)]
     per = max(len(c) for c in cands)
     outs = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("UWSPR_K4_GROUPS", flag)
+    for groups, stage_grid in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("UWSPR_K4_GROUPS", groups)        # lag sweeps: k4_group vs k4_tonecorr
+        monkeypatch.setenv("UWSPR_K4_STAGE_GRID", stage_grid)  # freq/drift stages: k4_grid vs k4_tonecorr
         c = G.Context()
         try:
             outs.append(c.demod_batch(frames, cands, max_per_frame=per))
         finally:
             c.close()
-    assert outs[0].tobytes() == outs[1].tobytes()
+    for o in outs[1:]:
+        assert outs[0].tobytes() == o.tobytes()
     assert (outs[0][:, 0]["symbols"] == vec["demod_symbols"]).all()
 
 
