@@ -20,7 +20,10 @@ __device__ __forceinline__ bool pr3_rt(int i) { return (kPr3[i >> 5] >> (i & 31)
 
 // ------------------------------------------------------------------- K5 fold
 // One lane per hypothesis, 162 sequential steps in symbol order: the
-// reference's accumulation order for totp / ss / fsum / f2sum.
+// reference's accumulation order for totp / ss / fsum / f2sum.  Kept as the A/B
+// alternative (UWSPR_K5_LANES=1) of the wave-per-hypothesis form below, which is
+// faster at every size measured (its row reads are coalesced; here each lane
+// walks its own 2.6 KB row).
 __global__ __launch_bounds__(256) void k5_fold(const dev_hyp *__restrict__ hyps,
                                                const float4 *__restrict__ p, int H,
                                                float symfac, float *__restrict__ sync,
@@ -216,7 +219,6 @@ void launch_prep_hyps(uwspr_ctx *c, const uwspr_hyp *abi, dev_hyp *out, int H) {
 // Stage s consumes the metrics of the hypotheses stage s-1 generated and
 // emits the next ones; hypotheses per candidate: S0 5, S1 5, S2 2, S3 5, S4 5,
 // S5 17 (cc:409-482).  One thread per candidate slot.
-__device__ __constant__ int kHpc[6] = {5, 5, 2, 5, 5, 17};
 
 __device__ inline void emit(dev_hyp *h, const cand_state &st, bool on, int lag, float f0,
                             float drift) {

@@ -562,7 +562,6 @@ extern "C" int uwspr_sync_and_demodulate_batch(uwspr_ctx *c, const float *frames
     if (k.mode < 0 || k.mode > 2) return fail(c, UWSPR_ERR_ARG, "calls[%d].mode=%d", q, k.mode);
     if (k.symfac != 50) return fail(c, UWSPR_ERR_UNSUPPORTED, "calls[%d].symfac=%d (the path uses 50)", q, k.symfac);
     if (k.frame < 0 || k.frame >= B) return fail(c, UWSPR_ERR_ARG, "calls[%d].frame=%d", q, k.frame);
-    if (q > 0 && k.frame < calls[q - 1].frame) return fail(c, UWSPR_ERR_ARG, "calls must be grouped by non-decreasing frame");
     int ifmin = k.ifmin, ifmax = k.ifmax, lagmin = k.lagmin, lagmax = k.lagmax;
     float fstep = k.fstep;
     if (k.mode == 0) { ifmin = 0; ifmax = 0; fstep = 0.0f; }

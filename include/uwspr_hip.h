@@ -173,9 +173,9 @@ int uwspr_fdr_keep_syncgrid(uwspr_ctx *ctx, int ncand_cap);
 int uwspr_fdr_read_syncgrid(uwspr_ctx *ctx, int B, float *grid);
 
 /* ---- fine sweep: core of sync_and_demodulate, cc:126-256 ---------------- */
-/* One metric per (freq, lag, drift) hypothesis.  hyps must be grouped by
- * non-decreasing frame index.  sync: [H]; symbols: [H][162] soft symbols
- * (cc:240-254) or NULL to skip them (modes 0/1). */
+/* One metric per (freq, lag, drift) hypothesis, in any order (grouping them by
+ * frame keeps a frame's samples in L2).  sync: [H]; symbols: [H][162] soft
+ * symbols (cc:240-254) or NULL to skip them (modes 0/1). */
 int uwspr_sync_sweep(uwspr_ctx *ctx, const float *frames, int B,
                      const uwspr_hyp *hyps, int H, int where, float *sync,
                      uint8_t *symbols);

@@ -394,3 +394,58 @@ def test_context_rejects_bad_parameters(G):
     with pytest.raises(N.UwsprError) as e:
         G.Context(halfbandwidth=187)     # GRC XML default: the reference reads out of bounds
     assert e.value.status == -2
+
+
+def test_argument_errors_are_status_codes(ctx, G, frames):
+    """Bad calls come back as UWSPR_ERR_ARG with a message; nothing aborts the process."""
+    import ctypes as C
+    N = G.native
+    L = N.lib()
+    fr = np.ascontiguousarray(frames[:1])
+    sync = np.zeros(4, np.float32)
+    hy = np.zeros(1, N.HYP_DTYPE)
+    hy["frame"] = 3          # only one frame in the batch
+    rc = L.uwspr_sync_sweep(ctx.h, C.c_void_p(fr.ctypes.data), 1, C.c_void_p(hy.ctypes.data), 1, N.HOST,
+                            C.c_void_p(sync.ctypes.data), None)
+    assert rc == -6 and b"frame" in L.uwspr_last_error(ctx.h)
+    assert L.uwspr_sync_sweep(ctx.h, None, 1, C.c_void_p(hy.ctypes.data), 1, N.HOST,
+                              C.c_void_p(sync.ctypes.data), None) == -6
+    assert L.uwspr_fdr_read_syncgrid(ctx.h, 1, C.c_void_p(sync.ctypes.data)) == -6   # grid not kept
+    calls = np.zeros(1, N.CALL_DTYPE)
+    calls["mode"] = 7
+    res = np.zeros(1, N.RESULT_DTYPE)
+    assert L.uwspr_sync_and_demodulate_batch(ctx.h, C.c_void_p(fr.ctypes.data), 1, N.HOST,
+                                             C.c_void_p(calls.ctypes.data), 1,
+                                             C.c_void_p(res.ctypes.data)) == -6
+    calls["mode"] = 1; calls["symfac"] = 64; calls["lagstep"] = 1
+    assert L.uwspr_sync_and_demodulate_batch(ctx.h, C.c_void_p(fr.ctypes.data), 1, N.HOST,
+                                             C.c_void_p(calls.ctypes.data), 1,
+                                             C.c_void_p(res.ctypes.data)) == -3
+    # the context is still usable afterwards
+    assert len(ctx.fdr_batch(fr)[0]) >= 1
+
+
+def test_nonlinear_candidate_through_the_call_form(ctx, G, oracle, frames):
+    """sync_and_demodulate() with a nonlinear candidate (t = 0 rule) in all three modes."""
+    N = G.native
+    calls = np.zeros(3, N.CALL_DTYPE)
+    cand = np.zeros(1, oracle.CAND_DTYPE)[0]
+    cand["m_type"] = 1; cand["V1"] = 2.0; cand["V2"] = -1.0; cand["p1"] = 0; cand["p2"] = 250
+    specs = [(1, 0.4, 0, 0, 0.0, 300, 236, 364, 32, 0.0, 0), (1, 0.4, -2, 2, 0.25, 300, 0, 0, 64, 0.0, 1),
+             (1, 0.4, 0, 0, 0.0, 364, 0, 0, 16, 0.0, 2)]
+    for q, s in enumerate(specs):
+        c = calls[q]
+        c["frame"], c["f1"], c["ifmin"], c["ifmax"], c["fstep"], c["shift1"] = s[:6]
+        c["lagmin"], c["lagmax"], c["lagstep"], c["drift1"], c["mode"] = s[6:]
+        c["symfac"] = 50
+        for k in ("m_type", "V1", "V2", "p1", "p2"):
+            c["candidate"][k] = cand[k]
+    res = ctx.sync_and_demodulate(frames, calls)
+    for q, s in enumerate(specs):
+        sy, sh, f1, y = oracle.sync_and_demodulate(cand, 1500, frames[s[0]], s[1], s[2], s[3], s[4],
+                                                   s[5], s[6], s[7], s[8], s[9], 50, s[10])
+        assert np.float32(sy).tobytes() == res[q]["sync"].tobytes()
+        if s[10] <= 1:
+            assert sh == res[q]["shift1"] and np.float32(f1).tobytes() == res[q]["f1"].tobytes()
+        else:
+            assert (y == res[q]["symbols"]).all()
