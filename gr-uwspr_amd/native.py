@@ -144,6 +144,14 @@ def lib():
         return _lib
     if not os.path.exists(LIBPATH):
         build()
+    # One HIP/HSA runtime per process: PyTorch bundles its own libamdhip64.so.7 /
+    # libhsa-runtime64 and this library is linked against /opt/rocm's (same SONAME).
+    # Whichever is loaded first serves both; two live copies leave the second one
+    # without a device.  Load torch's first whenever torch is going to be used.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     L = C.CDLL(LIBPATH)
     vp, ip = C.c_void_p, C.c_int
     L.uwspr_ctx_create.argtypes = [C.POINTER(Params), ip, C.POINTER(vp)]
