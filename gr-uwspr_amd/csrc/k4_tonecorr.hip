@@ -168,9 +168,11 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
       *reinterpret_cast<float2 *>(&lds[(4 * t + segq) * K4_ROWDW + 2 * kk]) = stage[t];
     wave_lds_fence();
     if (ch < 15) load_chunk(ch + 1);
+    float2 xnext = *reinterpret_cast<const float2 *>(&lds[pr * K4_ROWDW]);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-      const float2 x = *reinterpret_cast<const float2 *>(&lds[pr * K4_ROWDW + 2 * k]);
+      const float2 x = xnext;  // the read of sample k+1 is in flight during step k
+      if (k < 15) xnext = *reinterpret_cast<const float2 *>(&lds[pr * K4_ROWDW + 2 * (k + 1)]);
 #pragma unroll
       for (int j = 0; j < T; j++) {
         // cc:206-207, left to right
@@ -357,11 +359,10 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
     }
     wave_lds_fence();
     if (ch < 15) load_chunk(ch + 1);
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      // the NL lags of this sample slot are contiguous: 16-byte reads
+    // the NL lags of a sample slot are contiguous (16-byte reads); the reads of step k+1
+    // are issued before the arithmetic of step k so their LDS latency is covered
+    auto read_slot = [&](int k, float2 (&x)[NLP]) {
       const float *slot = &lds[pr * ROWDW + k * NLP * 2];
-      float2 x[NLP];
 #pragma unroll
       for (int q = 0; q < NLP / 2; q++) {
         if (2 * q + 1 < NL || (NL & 1) == 0) {
@@ -371,14 +372,22 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
           x[2 * q] = *reinterpret_cast<const float2 *>(slot + 4 * q);
         }
       }
+    };
+    float2 xc[NLP], xn[NLP];
+    read_slot(0, xc);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (k < 15) read_slot(k + 1, xn);
 #pragma unroll
       for (int l = 0; l < NL; l++) {
-        inp[l] = (inp[l] + x[l].x * c) + x[l].y * s;     // cc:206
-        quad[l] = (quad[l] - x[l].x * s) + x[l].y * c;   // cc:207
+        inp[l] = (inp[l] + xc[l].x * c) + xc[l].y * s;     // cc:206
+        quad[l] = (quad[l] - xc[l].x * s) + xc[l].y * c;   // cc:207
       }
-      const float nc = c * cd - s * sd;                  // cc:193-195
+      const float nc = c * cd - s * sd;                    // cc:193-195
       const float ns = c * sd + s * cd;
       c = nc; s = ns;
+#pragma unroll
+      for (int l = 0; l < NLP; l++) xc[l] = xn[l];
     }
   }
 
