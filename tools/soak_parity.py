@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Soak: whole pipeline (FDR + schedule) on many frames at mixed SNRs, GPU vs the CPU
+oracle, every candidate of every frame.  usage: soak_parity.py [nframes] [halfbandwidth]"""
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import gr_uwspr_amd as G  # noqa: E402
+import oracle_py as O  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    hbw = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    snrs = [-32.0, -28.0, -26.0, -24.0, -20.0, -10.0, None]
+    parts = []
+    for k, snr in enumerate(snrs):
+        m = (n + len(snrs) - 1) // len(snrs)
+        fr = G.synth.make_frames(m, seed=5000 + 100 * k, snr_db=snr, halfbandwidth=hbw)
+        if snr == -32.0:
+            fr[: m // 2] = (np.random.default_rng(9).standard_normal(fr[: m // 2].shape) * 0.5).astype(np.float32)
+        parts.append(fr)
+    frames = np.concatenate(parts)[:n]
+    per = 4
+    ctx = G.Context(halfbandwidth=hbw)
+    t0 = time.time()
+    cands, out = ctx.pipeline_batch(frames, max_per_frame=per)
+    tg = time.time() - t0
+    O.lib(); O.pr3()
+    nw = min(16, len(os.sched_getaffinity(0)))
+    fdrs = [O.FDR(halfbandwidth=hbw) for _ in range(nw)]
+    bad = []
+
+    def check(args):
+        w, b = args
+        exp = fdrs[w].transform(frames[b])
+        msgs = []
+        if len(exp) != len(cands[b]):
+            return [(b, "npk", len(exp), len(cands[b]))]
+        for j, (a, e) in enumerate(zip(cands[b], exp)):
+            for k in ("m_type", "shift"):
+                if int(a[k]) != int(e[k]):
+                    msgs.append((b, j, k, int(a[k]), int(e[k])))
+            if np.float32(a["freq"]).tobytes() != np.float32(e["freq"]).tobytes():
+                msgs.append((b, j, "freq", float(a["freq"]), float(e["freq"])))
+            if np.float32(a["sync"]).tobytes() != np.float32(e["sync"]).tobytes():
+                msgs.append((b, j, "sync", float(a["sync"]), float(e["sync"])))
+            if abs(float(a["snr"]) - float(e["snr"])) > 1e-5 * abs(float(e["snr"])) + 1e-6:
+                msgs.append((b, j, "snr", float(a["snr"]), float(e["snr"])))
+            if int(e["m_type"]) == 1 and any(a[k] != e[k] for k in ("V1", "V2", "p1", "p2")):
+                msgs.append((b, j, "slm"))
+            if j < per:
+                d = O.demod_candidate(e, 1500, frames[b])
+                o = out[b, j]
+                if int(o["worth_a_try"]) != d["worth_a_try"] or int(o["shift1"]) != d["shift1"]:
+                    msgs.append((b, j, "sched", int(o["shift1"]), d["shift1"]))
+                for k in ("f1", "drift1", "sync1"):
+                    if np.float32(o[k]).tobytes() != np.float32(d[k]).tobytes():
+                        msgs.append((b, j, k, float(o[k]), float(d[k])))
+                if d["worth_a_try"] and not (o["symbols"] == d["symbols"]).all():
+                    msgs.append((b, j, "symbols", int((o["symbols"] != d["symbols"]).sum())))
+        return msgs
+
+    t0 = time.time()
+    with ThreadPoolExecutor(nw) as ex:
+        for m in ex.map(check, [(i % nw, i) for i in range(n)]):
+            bad += m
+    tc = time.time() - t0
+    ncand = sum(len(c) for c in cands)
+    print("frames %d, candidates %d (max %d per frame), GPU %.2f s (host pointers), oracle %.1f s on %d threads"
+          % (n, ncand, max(len(c) for c in cands), tg, tc, nw))
+    print("mismatches:", len(bad))
+    for m in bad[:20]:
+        print("  ", m)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
