@@ -199,6 +199,20 @@ def main():
     prof = prof_sum()
     prof["tonecorr"] = prof_k4["tonecorr"]
     prof_all(False)
+    # single-stream pass (untimed for `value`): K4 launch durations without other streams'
+    # kernels sharing the CUs; this is the figure a `--streams 1` rocprofv3 trace shows
+    k4_single = None
+    if ns > 1:
+        lanes[0]["ctx"].prof_enable(("tonecorr",))
+        lanes[0]["ctx"].prof_read()
+        n1 = min(args.steps, 20)
+        for _ in range(n1):
+            step_no[0] = 0
+            step()
+        barrier()
+        k4_single = lanes[0]["ctx"].prof_read()["tonecorr"]
+        k4_single["steps"] = n1
+        lanes[0]["ctx"].prof_enable(False)
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64,
                           device="cpu" if dist.get_backend() == "gloo" else dev)
@@ -270,6 +284,13 @@ def main():
                          "k4_sum_of_launch_ms_per_step": k4["ms"] / args.steps,
                          "accounting": "launches from %d streams may overlap: achieved = bytes / union of the "
                                        "launches' HIP-event intervals" % ns,
+                         "single_stream": None if not k4_single else {
+                             "avg_launch_ms": k4_single["ms"] / max(k4_single["launches"], 1),
+                             "k4_ms_per_step": k4_single["ms"] / k4_single["steps"],
+                             "achieved": fine_hyps * HYP_BYTES * k4_single["steps"] / (k4_single["ms"] * 1e-3) / 1e9,
+                             "frac": fine_hyps * HYP_BYTES * k4_single["steps"] / (k4_single["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "note": "same step on one stream: launch durations comparable with "
+                                     "profiles/*_streams1 rocprofv3 kernel trace"},
                          "fp32_tops": fine_hyps * HYP_FLOP * args.steps / (k4_busy_ms * 1e-3) / 1e12 if k4_busy_ms > 0 else 0.0,
                          "fp32_nofma_peak_tops": FP32_NOFMA_PEAK_TOPS},
             "kernels": kern,
