@@ -116,7 +116,7 @@ def main():
     ns = max(1, args.streams)
     lanes = []
     for k in range(ns):
-        st = torch.cuda.Stream(device=dev) if ns > 1 else torch.cuda.current_stream()
+        st = torch.cuda.Stream(device=dev)
         cx = G.Context(device=local)
         cx.set_stream(st.cuda_stream)
         lanes.append({"stream": st, "ctx": cx,

@@ -36,6 +36,7 @@ class Context:
         self._chk(self.L.uwspr_get_info(self.h, C.byref(self.info)))
         self.fl, self.maxfreqs = fl, maxfreqs
         self._keep = []
+        self._stream_ptr = None
 
     def close(self):
         if getattr(self, "h", None):
@@ -59,12 +60,20 @@ class Context:
             assert frames.is_cuda and frames.is_contiguous() and frames.dtype.is_floating_point
             assert frames.element_size() == 4
             B = frames.numel() // (2 * self.fl)
+            if self._stream_ptr is None:
+                # the library runs on the context's own stream: whatever torch queued on
+                # its current stream to produce `frames` must have finished first
+                import torch
+                torch.cuda.current_stream(frames.device).synchronize()
             return C.c_void_p(frames.data_ptr()), B, N.DEVICE, frames
         a = np.ascontiguousarray(frames, dtype=np.float32).reshape(-1, self.fl, 2)
         return C.c_void_p(a.ctypes.data), a.shape[0], N.HOST, a
 
     def set_stream(self, stream_ptr):
+        """Run on a caller's hipStream_t (e.g. torch.cuda.Stream().cuda_stream); the caller
+        then owns the ordering against its own work on that stream.  None/0 = own stream."""
         self._chk(self.L.uwspr_set_stream(self.h, C.c_void_p(stream_ptr)))
+        self._stream_ptr = stream_ptr or None
 
     def synchronize(self):
         self._chk(self.L.uwspr_synchronize(self.h))
@@ -76,8 +85,12 @@ class Context:
             import torch
             B, nin = audio.shape
             out = torch.empty((B, self.fl, 2), dtype=torch.float32, device=audio.device)
+            if self._stream_ptr is None:
+                torch.cuda.current_stream(audio.device).synchronize()
             self._chk(self.L.uwspr_frontend_batch(self.h, C.c_void_p(audio.data_ptr()), B, nin, N.DEVICE,
                                                   C.c_void_p(out.data_ptr())))
+            if self._stream_ptr is None:
+                self.synchronize()
             return out
         a = np.ascontiguousarray(audio, dtype=np.float32)
         a = a.reshape(1, -1) if a.ndim == 1 else a

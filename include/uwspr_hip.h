@@ -133,9 +133,12 @@ void uwspr_ctx_destroy(uwspr_ctx *ctx);
 const char *uwspr_last_error(const uwspr_ctx *ctx);
 const char *uwspr_status_string(int status);
 int uwspr_get_info(const uwspr_ctx *ctx, uwspr_info *info);
-/* Run on a caller-owned hipStream_t (NULL = the context's own stream).  All
- * calls are asynchronous on that stream when where==UWSPR_DEVICE and complete
- * before returning when where==UWSPR_HOST. */
+/* Run on a caller-owned hipStream_t (NULL = the context's own, non-blocking
+ * stream).  All calls are asynchronous on that stream when where==UWSPR_DEVICE
+ * and complete before returning when where==UWSPR_HOST.  Device inputs written
+ * by work on ANOTHER stream must be complete (or ordered by the caller, e.g. by
+ * passing that stream here) before the call: the library adds no cross-stream
+ * dependency of its own. */
 int uwspr_set_stream(uwspr_ctx *ctx, void *hip_stream);
 int uwspr_synchronize(uwspr_ctx *ctx);
 
