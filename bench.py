@@ -227,9 +227,15 @@ def main():
     live = npk > 0
     worth = out[:, 0]["worth_a_try"] > 0
     fine_hyps = int(10 * live.sum() + 2 * (live & top_lin).sum() + 27 * worth.sum())
-    decoded = 0
-    for b in range(min(B, 64)):
-        decoded += 1 if G.decode_candidate(out[b, 0]) is not None else 0
+    # host tail: deinterleave + Fano of the batch's top candidates on the
+    # host cores; reported beside `value`, never inside the timed region
+    nthr = min(16, len(os.sched_getaffinity(0)))
+    G.decode_batch(out[:8, 0], nthreads=nthr)
+    t_h = time.perf_counter()
+    _, _, okv = G.decode_batch(out[:, 0], nthreads=nthr)
+    host_tail = {"records": int(B), "decoded": int(okv.sum()), "threads": nthr,
+                 "records_per_s": B / (time.perf_counter() - t_h)}
+    decoded = int(okv[:64].sum())
 
     frames_cpu = frames.cpu().numpy() if (rank == 0 and world == 1) else None
     # the same batch handed over as HOST buffers (what a GNU Radio block would do):
@@ -295,6 +301,7 @@ def main():
                          "fp32_nofma_peak_tops": FP32_NOFMA_PEAK_TOPS},
             "kernels": kern,
             "host_pointer_frames_per_s_pcie_inclusive": host_rate,
+            "host_tail_fano": host_tail,
             "ms_per_step_with_events_on_every_kernel": 1e3 * dt_all_events / args.steps,
         }
 

@@ -353,6 +353,21 @@ def decode_candidate(demod_rec):
     return (msg, idt.value) if ok else None
 
 
+def decode_batch(demod_recs, nthreads=0):
+    """demod_recs: DEMOD_DTYPE array (any shape). -> (messages [n,7] int8, idt [n] int32,
+    decoded [n] bool), record order kept; Fano runs on `nthreads` host threads."""
+    rec = np.ascontiguousarray(np.asarray(demod_recs, dtype=N.DEMOD_DTYPE).reshape(-1))
+    n = rec.size
+    msg = np.zeros((n, 7), np.int8)
+    idt = np.full(n, -1, np.int32)
+    ok = np.zeros(n, np.uint8)
+    rc = N.lib().uwspr_decode_batch(C.c_void_p(rec.ctypes.data), n, nthreads, C.c_void_p(msg.ctypes.data),
+                                    C.c_void_p(idt.ctypes.data), C.c_void_p(ok.ctypes.data))
+    if rc < 0:
+        raise N.UwsprError(rc, "uwspr_decode_batch")
+    return msg, idt, ok.astype(bool)
+
+
 def unpack_message(message7):
     m = np.ascontiguousarray(message7, dtype=np.int8)
     buf = C.create_string_buffer(32)

@@ -18,6 +18,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/uwspr_hip.h"
@@ -176,6 +178,42 @@ extern "C" int uwspr_decode_candidate(const uwspr_demod_out *d, int8_t *message7
     }
   }
   return 0;
+}
+
+// Candidates are independent (cc:389 loops over them one by one), so a batch of
+// records is decoded by a pool of host threads pulling indices from one counter;
+// record i's result does not depend on the thread count.
+extern "C" int uwspr_decode_batch(const uwspr_demod_out *d, int n, int nthreads, int8_t *messages,
+                                  int32_t *idt_used, uint8_t *decoded) {
+  if (n < 0 || (n > 0 && (!d || !messages || !decoded))) return UWSPR_ERR_ARG;
+  if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > n) nthreads = n > 0 ? n : 1;
+  std::atomic<int> next(0), good(0);
+  auto work = [&]() {
+    int ok = 0;
+    for (;;) {
+      const int i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= n) break;
+      int32_t idt = -1;
+      const int r = uwspr_decode_candidate(&d[i], messages + 7 * (size_t)i, &idt);
+      decoded[i] = (uint8_t)r;
+      if (!r) memset(messages + 7 * (size_t)i, 0, 7);
+      if (idt_used) idt_used[i] = idt;
+      ok += r;
+    }
+    good.fetch_add(ok, std::memory_order_relaxed);
+  };
+  if (nthreads == 1) {
+    work();
+  } else {
+    std::vector<std::thread> pool;
+    pool.reserve(nthreads - 1);
+    for (int t = 1; t < nthreads; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+  }
+  return good.load();
 }
 
 // ---- WSPR message unpack (types 1 and 2; type 3 without a hash table) ------

@@ -3,7 +3,7 @@
 // candidates PDU in, one 7-byte blob PDU out per decoded candidate, in candidate
 // order.  The refinement schedule S0..S5 runs on the GPU for all candidates of
 // the frame in one uwspr_demod_batch call; the gate/retry/Fano loop (cc:457-490)
-// is replayed on the host by uwspr_decode_candidate.
+// is replayed on the host by uwspr_decode_batch (uwspr_decode_candidate per record).
 #include <stdio.h>
 #include <time.h>
 
@@ -67,10 +67,15 @@ class sync_and_demodulate_impl : public sync_and_demodulate {
                                npk, out.data());
     if (rc != UWSPR_OK)
       throw std::runtime_error(std::string("uwspr.sync_and_demodulate: ") + uwspr_last_error(d_ctx));
-    for (int j = 0; j < npk; j++) {  // cc:389
-      int8_t m7[7];
-      int32_t idt = -1;
-      if (!uwspr_decode_candidate(&out[j], m7, &idt)) continue;
+    // cc:389: the candidates are independent, so their Fano runs go to the host
+    // cores together; results are published in candidate order as the reference does
+    std::vector<int8_t> msgs((size_t)npk * 7);
+    std::vector<uint8_t> got(npk);
+    if (uwspr_decode_batch(out.data(), npk, 0, msgs.data(), nullptr, got.data()) < 0)
+      throw std::runtime_error("uwspr.sync_and_demodulate: decode_batch");
+    for (int j = 0; j < npk; j++) {
+      if (!got[j]) continue;
+      const int8_t *m7 = &msgs[(size_t)j * 7];
       d_framecount++;  // cc:492
       if (d_log) {
         const candidate_t &c = in->candidates[j];

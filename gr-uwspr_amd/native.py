@@ -56,7 +56,7 @@ def build(force=False, verbose=False):
     deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     deps.append(os.path.join(_HERE, "..", "include", "uwspr_hip.h"))
     extra = os.environ.get("UWSPR_EXTRA_HIPFLAGS", "").split()   # experiments only
-    cmd = [_hipcc()] + HIPFLAGS + extra + ["-shared"] + srcs + ["-o", LIBPATH]
+    cmd = [_hipcc()] + HIPFLAGS + extra + ["-shared", "-pthread"] + srcs + ["-o", LIBPATH]
     stamp = LIBPATH + ".cmd"
     same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
     if force or not same_cmd or _stale(LIBPATH, deps):
@@ -130,7 +130,7 @@ ABI_SYMBOLS = [
     "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
     "uwspr_sync_sweep", "uwspr_sync_grid", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
     "uwspr_pipeline_batch", "uwspr_pack_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
-    "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_unpack_message",
+    "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_decode_batch", "uwspr_unpack_message",
     "uwspr_c2_read",
 ]
 
@@ -185,6 +185,8 @@ def lib():
                                     C.POINTER(C.c_uint32), ip, C.c_uint32]
     L.uwspr_fano_encode.argtypes = [vp, vp, C.c_uint32]
     L.uwspr_decode_candidate.argtypes = [vp, vp, C.POINTER(C.c_int32)]
+    L.uwspr_decode_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+    L.uwspr_decode_batch.restype = C.c_int
     L.uwspr_unpack_message.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.uwspr_c2_read.argtypes = [C.c_char_p, vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     _lib = L

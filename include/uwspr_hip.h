@@ -284,6 +284,12 @@ int uwspr_fano_encode(uint8_t *symbols, const uint8_t *data, uint32_t nbytes);
  * Fano in reference order.  returns 1 and fills message7 on decode, else 0. */
 int uwspr_decode_candidate(const uwspr_demod_out *d, int8_t *message7,
                            int32_t *idt_used);
+/* The same for n records on `nthreads` host threads (<= 0: one per hardware
+ * thread): the per-candidate loop of cc:389 with its Fano calls spread over the
+ * host cores.  messages [n][7] (zero when not decoded), idt_used [n] or NULL,
+ * decoded [n] = 0/1.  returns the number decoded (or UWSPR_ERR_ARG). */
+int uwspr_decode_batch(const uwspr_demod_out *d, int n, int nthreads,
+                       int8_t *messages, int32_t *idt_used, uint8_t *decoded);
 /* lib/helpers.cc unpk_ (called at WSPR_unpacker_impl.cc:129), without the
  * on-disk hash table: "CALL GRID dBm" into out (>= 23 bytes). returns 0 ok. */
 int uwspr_unpack_message(const int8_t *message7, char *out, size_t out_len);

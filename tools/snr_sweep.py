@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""BASELINE configs[4]: the reference's example recording (examples/150613_1920.wav,
+committed as tests/golden/150613_1920_int16.npz) + AWGN over an SNR sweep, decoded end
+to end: K0 front-end -> FDR -> S0..S5 schedule (GPU) -> deinterleave + Fano + unpack
+(host), beside the CPU path (oracle kernels + the same host tail) on the same frames.
+
+usage: snr_sweep.py [seeds_per_snr] [--json out.json]
+Prints one row per SNR: decode rate of `VE3EMB FN42 33`, GPU and CPU decode sets equal?,
+GPU and CPU seconds.  SNR is referred to 2500 Hz like WSPR reports; the recording's own
+SNR is estimated from its 375 S/s spectrum and noise is added up to the target.
+"""
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import gr_uwspr_amd as G  # noqa: E402
+import oracle_py as O  # noqa: E402
+
+WANT = "VE3EMB FN42 33"
+PER = 4            # candidates per frame taken through the schedule
+SNRS = (-20.0, -22.0, -24.0, -26.0, -28.0, -30.0)
+
+
+def estimate_native(frame, f1):
+    """(signal power, noise density per Hz) of the 375 S/s complex frame around f1."""
+    z = frame[:, 0].astype(np.float64) + 1j * frame[:, 1].astype(np.float64)
+    n = z.size
+    Z = np.fft.fft(z) / n
+    f = np.fft.fftfreq(n, 1 / 375.0)
+    p = np.abs(Z) ** 2                       # mean-square contribution per bin
+    binw = 375.0 / n
+    sig = np.abs(f - f1) <= 4.0
+    ref = (np.abs(f - f1) > 8.0) & (np.abs(f) < 50.0)
+    n0 = np.median(p[ref]) / np.log(2.0) / binw   # exponential bins: mean = median / ln 2
+    ps = p[sig].sum() - n0 * binw * sig.sum()
+    return ps, n0
+
+
+def decode_texts(rec):
+    dec = G.decode_candidate(rec)
+    return None if dec is None else G.unpack_message(dec[0])[1]
+
+
+def cpu_decode(fdr, frame):
+    texts = []
+    for c in fdr.transform(frame)[:PER]:
+        d = O.demod_candidate(c, 1500, frame)
+        rec = np.zeros(1, G.native.DEMOD_DTYPE)[0]
+        for k in ("f1", "drift1", "sync1", "shift1", "worth_a_try", "jig_sync", "jig_rms", "jig_shift", "symbols"):
+            rec[k] = d[k]
+        t = decode_texts(rec)
+        if t is not None:
+            texts.append(t)
+    return texts
+
+
+def main():
+    seeds = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 8
+    jpath = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+    x = np.load(os.path.join(ROOT, "tests", "golden", "150613_1920_int16.npz"))["x"].astype(np.float32) / 32768.0
+    ctx = G.Context()
+    O.lib(); O.pr3()
+    nw = min(16, len(os.sched_getaffinity(0)))
+    fdrs = [O.FDR() for _ in range(nw)]
+    clean = ctx.frontend(x[None])
+    cands, out = ctx.pipeline_batch(clean, max_per_frame=PER)
+    f1 = None
+    for j in range(min(PER, len(cands[0]))):
+        if decode_texts(out[0, j]) == WANT:
+            f1 = float(out[0, j]["f1"])
+            break
+    assert f1 is not None, "the clean recording must decode"
+    ps, n0 = estimate_native(clean[0], f1)
+    native = 10 * np.log10(ps / (n0 * 2500.0))
+    print("recording: %s at %+.2f Hz, native SNR %.1f dB in 2500 Hz" % (WANT, f1, native))
+    rows = []
+    for snr in SNRS:
+        n0_target = ps / (2500.0 * 10 ** (snr / 10.0))
+        sigma = np.sqrt(max(n0_target - n0, 0.0) * 12000.0)     # real AWGN at 12 kS/s: density sigma^2/12000 per Hz
+        audio = np.empty((seeds, x.size), np.float32)
+        for s in range(seeds):
+            rng = np.random.Generator(np.random.Philox(int(1000 * -snr) + s))
+            audio[s] = x + sigma * rng.standard_normal(x.size).astype(np.float32)
+        t0 = time.time()
+        frames = ctx.frontend(audio)
+        cands, out = ctx.pipeline_batch(frames, max_per_frame=PER)
+        msg, _, okv = G.decode_batch(out, nthreads=nw)      # [seeds*PER] records, host threads
+        gpu_texts = []
+        for b in range(seeds):
+            gpu_texts.append([G.unpack_message(msg[b * PER + j])[1] for j in range(min(PER, len(cands[b])))
+                              if okv[b * PER + j]])
+        tg = time.time() - t0
+        t0 = time.time()
+        with ThreadPoolExecutor(nw) as ex:
+            cpu_texts = list(ex.map(lambda a: cpu_decode(fdrs[a % nw], frames[a]), range(seeds)))
+        tc = time.time() - t0
+        ok = sum(WANT in t for t in gpu_texts)
+        false_dec = sum(len([u for u in t if u != WANT]) for t in gpu_texts)
+        same = gpu_texts == cpu_texts
+        rows.append({"snr_db": snr, "frames": seeds, "decoded": ok, "other_decodes": false_dec,
+                     "gpu_equals_cpu": same, "gpu_s": tg, "cpu_s": tc, "cpu_threads": nw})
+        print("SNR %5.1f dB: %2d/%d decoded, %d other decodes, GPU==CPU %s, GPU %.1f ms (host audio in, front-end "
+              "+ search + Fano), CPU %.1f ms on %d threads (search + Fano, no front-end)"
+              % (snr, ok, seeds, false_dec, same, 1e3 * tg, 1e3 * tc, nw))
+    if jpath:
+        json.dump({"recording": "examples/150613_1920.wav", "native_snr_db": native, "rows": rows},
+                  open(jpath, "w"), indent=1)
+    print("mismatches:", sum(not r["gpu_equals_cpu"] for r in rows))
+    return 0 if all(r["gpu_equals_cpu"] for r in rows) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
