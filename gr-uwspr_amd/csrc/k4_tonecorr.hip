@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
   float *lds = lds_all[wv];
 
   const long long total = (long long)H * UWSPR_NSYM;
-  const long long g0 = ((long long)blockIdx.x * K4_WAVES + wv) * PPW;
+  const long long g0 = ((long long)xcd_swizzle(blockIdx.x, gridDim.x) * K4_WAVES + wv) * PPW;
   if (g0 >= total) return;  // wave-uniform; no workgroup barrier is used below
 
   // A wave's pairs span at most two hypotheses (162 > 64 >= PPW).
@@ -240,6 +240,17 @@ namespace uwspr {
 
 constexpr int K4G_WAVES = 2;
 
+#ifdef K4_STAMPS   // diagnostic build only: per-wave timeline of the last k4_group launch
+constexpr int K4_STAMP_WAVES = 16384;
+__device__ unsigned long long g_k4_stamps[K4_STAMP_WAVES * 4];
+#ifndef K4_STAMP_NL
+#define K4_STAMP_NL 5
+#endif
+#define K4_STAMP(slot) do { if (NL == K4_STAMP_NL && lane == 0 && gwave < K4_STAMP_WAVES) g_k4_stamps[gwave * 4 + (slot)] = wall_clock64(); } while (0)
+#else
+#define K4_STAMP(slot) do { } while (0)
+#endif
+
 template <int NL>
 __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
     const float2 *__restrict__ frames, int fl, int nframes, const dev_grp *__restrict__ grps,
@@ -255,8 +266,16 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
   float *lds = lds_all[wv];
 
   const long long total = (long long)G * UWSPR_NSYM;
-  const long long g0 = ((long long)blockIdx.x * K4G_WAVES + wv) * PPW;
+  const unsigned lblock = xcd_swizzle(blockIdx.x, gridDim.x);
+  const long long g0 = ((long long)lblock * K4G_WAVES + wv) * PPW;
   if (g0 >= total) return;  // wave-uniform
+#ifdef K4_STAMPS
+  const int gwave = lblock * K4G_WAVES + wv;
+  K4_STAMP(0);
+  if (NL == K4_STAMP_NL && lane == 0 && gwave < K4_STAMP_WAVES)
+    g_k4_stamps[gwave * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+                                 ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+#endif
 
   const int gA = (int)(g0 / UWSPR_NSYM);
   const int iA0 = (int)(g0 - (long long)gA * UWSPR_NSYM);
@@ -349,6 +368,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
 #pragma unroll
   for (int l = 0; l < NL; l++) { inp[l] = 0.0f; quad[l] = 0.0f; }
 
+  K4_STAMP(1);
   load_chunk(0);
   for (int ch = 0; ch < 16; ch++) {
     wave_lds_fence();
@@ -391,21 +411,23 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
     }
   }
 
+  K4_STAMP(2);
   if (g0 + pr < total) {
     const int nv = mineA ? nvA : nvB;
     const int hb = mineA ? A.hyp_base : Bg.hyp_base;
+    const uint32_t hm = mineA ? A.hmap : Bg.hmap;
 #pragma unroll
     for (int l = 0; l < NL; l++) {
       if (l < nv) {
         const float pj = ieee_sqrtf(inp[l] * inp[l] + quad[l] * quad[l]);  // cc:211
-        p_out[((long long)(hb + l) * UWSPR_NSYM + own_i) * 4 + tone] = pj;
+        p_out[((long long)(hb + (int)((hm >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = pj;
       }
     }
     // groups that are skipped produce zeros for their hypotheses
     const dev_grp &gy = mineA ? A : Bg;
     if (!(mineA ? okA : okB) && gy.nvalid > 0)
       for (int l = 0; l < gy.nvalid && l < NL; l++)
-        p_out[((long long)(gy.hyp_base + l) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
+        p_out[((long long)(gy.hyp_base + (int)((gy.hmap >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
   }
 }
 
@@ -423,6 +445,206 @@ void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_
   else if (NL == 6) hipLaunchKernelGGL(k4_group<6>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, grps, G, po);
   else hipLaunchKernelGGL(k4_group<8>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, grps, G, po);
 }
+
+// ---------------------------------------------------------------------------
+// Ring form of the lag group, for groups whose lags are ASCENDING and evenly
+// spaced by STEP samples (S3: shift1-32..+32 step 16; S5: the jiggered shifts,
+// step 8).  The NL windows of a (group, symbol) pair overlap almost entirely, so
+// the pair's samples a = n - (lag[0] + 256 i), 0 <= a < 256 + (NL-1) STEP, are
+// brought into LDS ONCE, as a ring of M = Q+1 slots of 16 samples, instead of
+// once per lag: 4 global loads and 4 LDS stores per lane and 16-sample chunk
+// instead of 4 NL.  Lag l at step k of chunk c reads a = 16 c + k + STEP l, i.e.
+// slot (c + q) mod M, column r with (q, r) = divmod(k + STEP l, 16) known at
+// compile time; the M slot addresses rotate once per chunk.  Arithmetic per
+// accumulator is exactly k4_group's (cc:193-195, 206-207).
+template <int NL, int STEP>
+__global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
+    const float2 *__restrict__ frames, int fl, int nframes, const dev_grp *__restrict__ grps,
+    int G, float *__restrict__ p_out) {
+  constexpr int PPW = 16;
+  constexpr int W = (NL - 1) * STEP;       // extra samples beyond the first lag's window
+  constexpr int Q = (15 + W) / 16;         // furthest slot a chunk reaches ahead
+  constexpr int M = Q + 1;                 // ring slots
+  constexpr int NSLOT = 16 + Q;            // slots a pair needs in all
+  constexpr int RS = 32 * M + 2;           // dwords per pair row (rows start on distinct bank pairs)
+  __shared__ __align__(16) float lds_all[K4G_WAVES][PPW * RS];
+
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float *lds = lds_all[wv];
+
+  const long long total = (long long)G * UWSPR_NSYM;
+  const unsigned lblock = xcd_swizzle(blockIdx.x, gridDim.x);
+  const long long g0 = ((long long)lblock * K4G_WAVES + wv) * PPW;
+  if (g0 >= total) return;  // wave-uniform
+
+  const int gA = (int)(g0 / UWSPR_NSYM);
+  const int iA0 = (int)(g0 - (long long)gA * UWSPR_NSYM);
+  const int sb = min(PPW, UWSPR_NSYM - iA0);  // pairs < sb belong to group gA
+  const dev_grp A = grps[gA];
+  const dev_grp Bg = grps[min(gA + 1, G - 1)];
+  const bool okA = A.frame >= 0 && A.frame < nframes;
+  const bool okB = (gA + 1 < G) && Bg.frame >= 0 && Bg.frame < nframes;
+  const int frA = okA ? A.frame : 0, frB = okB ? Bg.frame : 0;
+  const int nvA = okA ? A.nvalid : 0, nvB = okB ? Bg.nvalid : 0;
+  // first lag of the two groups; skipped groups point at safe samples
+  const int l0A = okA ? A.lag[0] : 1 - 256 * iA0;
+  const int l0B = okB ? Bg.lag[0] : 1;
+
+  const int pr = lane >> 2;
+  const int tone = lane & 3;
+  const bool mineA = pr < sb;
+  const int own_i = mineA ? iA0 + pr : pr - sb;
+  const int own_nb = (mineA ? l0A : l0B) + 256 * own_i;
+  const bool interior = __all((own_nb > 0) && (own_nb + 255 + 16 * Q < fl)  /* the loader fetches whole slots */);
+
+  // ---- this lane's tone phasor step (binary64 angle, cc:173-189) ------------
+  float cd, sd;
+  {
+    const dev_grp &gy = mineA ? A : Bg;
+    float fp;
+    if (gy.m_type == UWSPR_LINEAR) {
+      fp = (float)((double)gy.f0 +
+                   ((double)gy.drift / 2.0) * ((double)(float)own_i - 81.0) / 81.0);
+    } else {
+      fp = gy.f0 + gy.slmc;
+    }
+    const float delta = ((float)tone - 1.5f) * 1.46484375f;
+    double sn, cs;
+    sincos(kTwoPiDt * (double)(fp + delta), &sn, &cs);
+    cd = (float)cs;
+    sd = (float)sn;
+  }
+
+  // ---- cooperative loader: load j of a slot = pair 4j + lane/16, sample lane%16
+  const int kk = lane & 15;
+  const int segq = lane >> 4;
+  const float2 *src[4];   // sample a = kk of that pair's ring (fast path)
+  long long fbase[4];
+  int nfirst[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int pj = 4 * j + segq;
+    const bool sA = pj < sb;
+    fbase[j] = (long long)(sA ? frA : frB) * fl;
+    nfirst[j] = (sA ? l0A + 256 * (iA0 + pj) : l0B + 256 * (pj - sb)) + kk;
+    src[j] = frames + fbase[j] + nfirst[j];
+  }
+  float2 stage[4];
+  auto load_slot = [&](int sl) {
+    if (interior) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) stage[j] = src[j][16 * sl];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int n = nfirst[j] + 16 * sl;
+        const bool inr = (n > 0) && (n < fl);  // cc:205, sample 0 excluded
+        const float2 v = frames[fbase[j] + min(max(n, 0), fl - 1)];
+        stage[j] = inr ? v : make_float2(0.0f, 0.0f);
+      }
+    }
+  };
+  auto store_slot = [&](int pos) {   // pos = ring position (slot mod M), wave-uniform
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      *reinterpret_cast<float2 *>(&lds[(4 * j + segq) * RS + 2 * kk + 32 * pos]) = stage[j];
+  };
+
+  // prologue: slots 0..Q
+#pragma unroll
+  for (int sl = 0; sl <= Q; sl++) {
+    load_slot(sl);
+    store_slot(sl);
+  }
+
+  // ring positions of slots c..c+Q as this lane's row addresses
+  int sa[M];   // dword offsets into `lds` (kept as integers so the reads stay ds_read)
+#pragma unroll
+  for (int q = 0; q < M; q++) sa[q] = pr * RS + 32 * q;
+
+  float c = 1.0f, s = 0.0f;
+  float inp[NL], quad[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) { inp[l] = 0.0f; quad[l] = 0.0f; }
+
+  int wpos = 0;  // ring position that slot c + Q + 1 will overwrite (= position of slot c)
+  for (int ch = 0; ch < 16; ch++) {
+    // in flight during the chunk's arithmetic (the last chunk re-fetches the last slot: no
+    // branch here or after the arithmetic, or the compiler sinks the arithmetic past it)
+    load_slot(min(ch + Q + 1, NSLOT - 1));
+    wave_lds_fence();                      // the slots written so far are visible
+    float2 xc[NL], xn[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      xc[l] = *reinterpret_cast<const float2 *>(&lds[sa[(STEP * l) >> 4] + 2 * ((STEP * l) & 15)]);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      if (k < 15) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+          const int o = k + 1 + STEP * l;
+          xn[l] = *reinterpret_cast<const float2 *>(&lds[sa[o >> 4] + 2 * (o & 15)]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the reads of step k+1 ahead of step k's arithmetic
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        inp[l] = (inp[l] + xc[l].x * c) + xc[l].y * s;     // cc:206
+        quad[l] = (quad[l] - xc[l].x * s) + xc[l].y * c;   // cc:207
+      }
+      const float nc = c * cd - s * sd;                    // cc:193-195
+      const float ns = c * sd + s * cd;
+      c = nc; s = ns;
+#pragma unroll
+      for (int l = 0; l < NL; l++) xc[l] = xn[l];
+    }
+    // slot ch is finished with: its position takes slot ch + Q + 1, and the addresses rotate
+    wave_lds_fence();
+    store_slot(wpos);
+    wpos = (wpos + 1 == M) ? 0 : wpos + 1;
+    const int first = sa[0];
+#pragma unroll
+    for (int q = 0; q + 1 < M; q++) sa[q] = sa[q + 1];
+    sa[M - 1] = first;
+  }
+
+  if (g0 + pr < total) {
+    const int nv = mineA ? nvA : nvB;
+    const int hb = mineA ? A.hyp_base : Bg.hyp_base;
+    const uint32_t hm = mineA ? A.hmap : Bg.hmap;
+#pragma unroll
+    for (int l = 0; l < NL; l++) {
+      if (l < nv) {
+        const float pj = ieee_sqrtf(inp[l] * inp[l] + quad[l] * quad[l]);  // cc:211
+        p_out[((long long)(hb + (int)((hm >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = pj;
+      }
+    }
+    // groups that are skipped produce zeros for their hypotheses
+    const dev_grp &gy = mineA ? A : Bg;
+    if (!(mineA ? okA : okB) && gy.nvalid > 0)
+      for (int l = 0; l < gy.nvalid && l < NL; l++)
+        p_out[((long long)(gy.hyp_base + (int)((gy.hmap >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
+  }
+}
+
+// lags of every group must be lag[0] + l*step, l < nvalid (the schedule's S3 / S5 emitters)
+void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
+                          int NL, int step, int64_t nhyps, float4 *p) {
+  if (G <= 0) return;
+  prof_scope ps(c, UWSPR_K_TONECORR, nhyps);
+  const long long total = (long long)G * UWSPR_NSYM;
+  const long long waves = (total + 15) / 16;
+  const unsigned blocks = (unsigned)((waves + K4G_WAVES - 1) / K4G_WAVES);
+  const float2 *fr = (const float2 *)frames;
+  float *po = (float *)p;
+  dim3 blk(64 * K4G_WAVES);
+  if (NL == 5 && step == 16) hipLaunchKernelGGL((k4_ring<5, 16>), dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, grps, G, po);
+  else if (NL == 6 && step == 8) hipLaunchKernelGGL((k4_ring<6, 8>), dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, grps, G, po);
+  else launch_tonecorr_groups(c, frames, B, grps, G, NL <= 5 ? 5 : NL == 6 ? 6 : 8, nhyps, p);
+}
+
 
 }  // namespace uwspr
 
@@ -673,3 +895,11 @@ bool launch_tonecorr_grid(uwspr_ctx *c, const float *frames, int B, const uwspr_
 }
 
 }  // namespace uwspr
+
+#ifdef K4_STAMPS
+extern "C" int uwspr_debug_k4_stamps(unsigned long long *out, int nwaves) {
+  if (nwaves > uwspr::K4_STAMP_WAVES) nwaves = uwspr::K4_STAMP_WAVES;
+  hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(uwspr::g_k4_stamps), (size_t)nwaves * 32);
+}
+#endif

@@ -228,10 +228,10 @@ __device__ inline void emit(dev_hyp *h, const cand_state &st, bool on, int lag, 
 
 // the same hypotheses as a lag group (shared phasors in K4)
 __device__ inline void emit_group(dev_grp *g, const cand_state &st, bool on, float f0, float drift,
-                                  int hyp_base, const int *lags, int n) {
+                                  int hyp_base, const int *lags, int n, uint32_t hmap = 0x76543210u) {
   g->frame = on ? st.frame : -1;
   g->m_type = st.m_type; g->f0 = f0; g->drift = drift; g->slmc = st.slmc;
-  g->nvalid = n; g->hyp_base = hyp_base; g->_pad = 0;
+  g->nvalid = n; g->hyp_base = hyp_base; g->hmap = hmap;
   for (int l = 0; l < 8; l++) g->lag[l] = l < n ? lags[l] : lags[0];
 }
 
@@ -360,10 +360,24 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
       lags[idt] = st.shift1 + ii;
       emit(&ho[idt], st, st.worth != 0, lags[idt], st.f1, st.drift1);
     }
-    lags[17] = lags[16];
-    for (int g = 0; g < 3; g++)  // 17 jiggered shifts as three lag groups of 6, 6, 5
+    // The 17 jiggered shifts as three lag groups of 6, 6, 5 with ASCENDING, evenly spaced
+    // lags (shift1 - 64 + 8 m, m = 0..16), so that a group's windows overlap and K4 can keep
+    // them in one LDS ring.  Shift m is try idt = 2|m-8| - (m < 8): -64 -> 15, 0 -> 0, +64 -> 16.
+    for (int g = 0; g < 3; g++) {
+      const int n = g < 2 ? 6 : 5;
+      int gl[6], idt0 = 99;
+      int id[6];
+      for (int l = 0; l < n; l++) {
+        const int m = 6 * g + l, d = m - 8;
+        id[l] = d == 0 ? 0 : (d < 0 ? -2 * d - 1 : 2 * d);
+        gl[l] = st.shift1 + 8 * d;
+        idt0 = id[l] < idt0 ? id[l] : idt0;
+      }
+      uint32_t hmap = 0;
+      for (int l = 0; l < n; l++) hmap |= (uint32_t)(id[l] - idt0) << (4 * l);
       emit_group(&grps[slot * 3 + g], st, st.worth != 0, st.f1, st.drift1,
-                 slot * UWSPR_NJIG + 6 * g, lags + 6 * g, g < 2 ? 6 : 5);
+                 slot * UWSPR_NJIG + idt0, gl, n, hmap);
+    }
   }
   state[slot] = st;
 }

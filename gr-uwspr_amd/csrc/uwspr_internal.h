@@ -26,6 +26,19 @@ __host__ __device__ constexpr int pr3_bit(int k) { return (pr3_word(k >> 5) >> (
 __device__ __forceinline__ float ieee_sqrtf(float x) { return __builtin_sqrtf(x); }
 __device__ __forceinline__ float ieee_divf(float x, float y) { return x / y; }
 
+// Workgroups are dealt to the 8 XCDs round-robin by blockIdx, each XCD with a private
+// 4 MB L2.  This bijective remap hands every XCD a CONTIGUOUS range of logical blocks,
+// so the blocks that re-read the same symbol windows (the hypotheses of one candidate)
+// share one L2 instead of each missing in its own.  Pure placement: results unchanged.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nwg) {
+#ifdef UWSPR_NO_XCD_SWIZZLE
+  return bid;
+#else
+  const unsigned q = nwg >> 3, r = nwg & 7u, x = bid & 7u;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+#endif
+}
+
 // fine-grid hypothesis as the kernels consume it (24 B)
 struct dev_hyp {
   int32_t frame;   // <0: skip
@@ -44,9 +57,9 @@ struct dev_grp {
   int32_t m_type;
   float f0, drift, slmc;
   int32_t nvalid;    // lags in use (the kernel is instantiated for NL >= nvalid)
-  int32_t hyp_base;  // hypothesis index of lag[0]; lag[l] is hypothesis hyp_base + l
+  int32_t hyp_base;  // lag slot l is hypothesis hyp_base + ((hmap >> 4l) & 15)
   int32_t lag[8];
-  int32_t _pad;
+  uint32_t hmap;     // 0x76543210 when the slots are in hypothesis order
 };
 static_assert(sizeof(dev_grp) == 64, "dev_grp is one 64-byte record");
 
@@ -120,6 +133,7 @@ struct uwspr_ctx {
   uwspr_candidate *cur_cands; int32_t *cur_npk; uwspr_demod_out *cur_dout;
   int last_per_frame;
   bool use_lag_groups, use_stage_grid;
+  bool use_lag_ring;     // S3/S5 groups through the LDS-ring form (UWSPR_K4_RING=0: plain groups)
   size_t cap_slab; uint8_t *d_slab;
 
   int prof_mask;
@@ -141,6 +155,8 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
 // lag-group form: G groups, each instantiated for NL in {5, 6, 8} lags
 void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
                             int NL, int64_t nhyps, float4 *p);
+void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
+                          int NL, int step, int64_t nhyps, float4 *p);
 // grid form (one centre per frame, shared sample windows); false = does not fit, use the flat path
 bool launch_tonecorr_grid(uwspr_ctx *c, const float *frames, int B, const uwspr_candidate *centres,
                           int nf, const float *df, int ndrift, const float *ddrift, int nlag,

@@ -51,9 +51,9 @@ void run(int wgs_per_cu, int iters) {
 }
 
 int main() {
-  for (int w : {1, 2, 4, 8}) run<1, false>(w, 4096);
+  for (int w : {1, 2, 3, 4, 6, 8}) run<1, false>(w, 4096);
   for (int w : {1, 2, 4, 8}) run<4, false>(w, 1024);
-  for (int w : {1, 2, 4, 8}) run<1, true>(w, 4096);
+  for (int w : {1, 2, 3, 4, 6, 8}) run<1, true>(w, 4096);
   for (int w : {1, 2, 4}) run<4, true>(w, 1024);
   return 0;
 }
