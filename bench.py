@@ -170,6 +170,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         gathered = step()
+    t_enq = time.perf_counter() - t0     # host time to enqueue the K steps (before any wait)
     barrier()
     dt = time.perf_counter() - t0
     # K4 launches of different lanes may overlap in time: the family's busy time is
@@ -302,6 +303,7 @@ def main():
             "kernels": kern,
             "host_pointer_frames_per_s_pcie_inclusive": host_rate,
             "host_tail_fano": host_tail,
+            "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "ms_per_step_with_events_on_every_kernel": 1e3 * dt_all_events / args.steps,
         }
 
