@@ -276,14 +276,16 @@ def test_schedule_matches_oracle(ctx, oracle, frames, vec):
 
 
 def test_schedule_without_lag_groups_is_identical(G, frames, vec, monkeypatch):
-    """The schedule's lag sweeps run through k4_group (shared tone phasors) by
-    default and through k4_tonecorr with UWSPR_K4_GROUPS=0: byte-identical output."""
+    """The schedule's lag sweeps run through k4_group / k4_ring (shared tone phasors, shared
+    windows) by default and through k4_tonecorr with UWSPR_K4_GROUPS=0: byte-identical output."""
     cands = [vec["cands"][b, :int(vec["npk"][b])] for b in range(4)]
     per = max(len(c) for c in cands)
     outs = []
-    for groups, stage_grid in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
+    for groups, stage_grid, ring in (("1", "1", "1"), ("0", "0", "1"), ("1", "0", "0"), ("0", "1", "0"),
+                                     ("1", "0", "1")):
         monkeypatch.setenv("UWSPR_K4_GROUPS", groups)        # lag sweeps: k4_group vs k4_tonecorr
         monkeypatch.setenv("UWSPR_K4_STAGE_GRID", stage_grid)  # freq/drift stages: k4_grid vs k4_tonecorr
+        monkeypatch.setenv("UWSPR_K4_RING", ring)            # S3/S5 lag groups: k4_ring vs k4_group
         c = G.Context()
         try:
             outs.append(c.demod_batch(frames, cands, max_per_frame=per))
@@ -449,3 +451,39 @@ def test_nonlinear_candidate_through_the_call_form(ctx, G, oracle, frames):
             assert sh == res[q]["shift1"] and np.float32(f1).tobytes() == res[q]["f1"].tobytes()
         else:
             assert (y == res[q]["symbols"]).all()
+
+
+def test_schedule_at_the_frame_edges(ctx, G, oracle):
+    """Transmissions that start at sample ~15 or run past the end of the frame: the
+    schedule's lags reach n <= 0 and n >= np (cc:205 skips them), which takes the
+    bounds-checked loaders of k4_group / k4_ring / k4_tonecorr instead of their
+    interior fast paths.  Hand-made candidates put the shifts right at the edges."""
+    base = G.synth.make_frames(2, seed=4711, snr_db=-12.0)
+    early = np.roll(base, -360, axis=1); early[:, -360:] = 0     # signal starts at sample 15
+    late = np.roll(base, 3400, axis=1); late[:, :3400] = 0       # last symbols fall off the end
+    frames = np.concatenate([early, late])
+    fdr = oracle.FDR()
+    cands = []
+    for b in range(4):
+        c = fdr.transform(frames[b])[:2].copy()
+        assert len(c) >= 1
+        extra = c[:1].copy()
+        extra["shift"] = 0 if b < 2 else 3775 + 128              # S0 lags -128..128 / beyond the end
+        cands.append(np.concatenate([c, extra]))
+    per = max(len(c) for c in cands)
+    out = ctx.demod_batch(frames, cands, max_per_frame=per)
+    worth = 0
+    for b in range(4):
+        for j in range(len(cands[b])):
+            d = oracle.demod_candidate(cands[b][j], 1500, frames[b])
+            o = out[b, j]
+            assert int(o["worth_a_try"]) == d["worth_a_try"] and int(o["shift1"]) == d["shift1"], (b, j)
+            for k in ("f1", "drift1", "sync1"):
+                assert np.float32(o[k]).tobytes() == np.float32(d[k]).tobytes(), (b, j, k)
+            if d["worth_a_try"]:
+                worth += 1
+                assert (o["symbols"] == d["symbols"]).all()
+                assert (o["jig_shift"] == d["jig_shift"]).all()
+                assert o["jig_sync"].tobytes() == d["jig_sync"].tobytes()
+    assert worth >= 4
+    assert min(int(out[b, j]["shift1"]) for b in range(2) for j in range(len(cands[b]))) < 64
