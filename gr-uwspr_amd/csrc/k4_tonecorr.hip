@@ -649,6 +649,184 @@ void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_gr
 }  // namespace uwspr
 
 // ---------------------------------------------------------------------------
+// Frequency-stage form, for the schedule's S1 / S4: the NF hypotheses of a
+// candidate slot share frame, lag and drift model and differ only in f0
+// (cc:416-419, 449-452).  A workgroup of four wavefronts -- one per TONE -- takes
+// 54 of the slot's 162 symbols, one symbol per lane, and every lane correlates its
+// symbol window against all NF frequencies: the window is staged and read once
+// for NF hypotheses.  When the per-symbol frequency does not depend on the symbol
+// (drift == 0 or the nonlinear model: the usual case), the phasor sequence
+// c[k], s[k] (cc:186-199) is the same for all symbols of a (frequency, tone) --
+// the reference caches it via `fplast` for the same reason -- so NF lanes of each
+// wave advance the NF recurrences, publish 16 steps at a time in LDS, and the
+// other lanes only multiply-accumulate: 8 NF ops per sample and lane plus 6 ops
+// on NF lanes, instead of 14 NF.  With a per-symbol frequency (drifting linear
+// model) every lane runs its own recurrences as k4_tonecorr does.  Arithmetic
+// per accumulator and per phasor is the reference's sequence in both cases.
+namespace uwspr {
+
+constexpr int K4F_PAIRS = 54;   // symbols per workgroup: 162 = 3 x 54
+constexpr int K4F_ROWDW = 34;   // dwords per staged row: 16 samples x 8 B + 8 B pad
+
+template <int NF>
+__global__ __launch_bounds__(256) void k4_fstage(
+    const float2 *__restrict__ frames, int fl, int nframes, const dev_hyp *__restrict__ hyps,
+    int nslots, float *__restrict__ p_out) {
+  __shared__ __align__(16) float smp[K4F_PAIRS * K4F_ROWDW];
+  __shared__ __align__(16) float2 tab[4][16][NF];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int tone = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned wg = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int slot = (int)(wg / 3u), part = (int)(wg % 3u);
+  if (slot >= nslots) return;  // workgroup-uniform
+
+  const dev_hyp h0 = hyps[(size_t)slot * NF];
+  float f0[NF];
+#pragma unroll
+  for (int q = 0; q < NF; q++) f0[q] = hyps[(size_t)slot * NF + q].f0;
+  const bool live = h0.frame >= 0 && h0.frame < nframes;
+  const int row = min(lane, K4F_PAIRS - 1);
+  const int own_i = part * K4F_PAIRS + row;       // this lane's symbol
+  const bool mine = lane < K4F_PAIRS;
+  if (!live) {                                     // skipped slot: its hypotheses read as zeros
+    if (mine)
+#pragma unroll
+      for (int q = 0; q < NF; q++)
+        p_out[(((long long)slot * NF + q) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
+    return;
+  }
+  const bool tabled = (h0.m_type != UWSPR_LINEAR) || (h0.drift == 0.0f);   // fp independent of the symbol
+  const float delta = ((float)tone - 1.5f) * 1.46484375f;                    // cc:148
+
+  // ---- loader: round r of a chunk = symbol 16 r + tid/16, sample tid%16 ----
+  const int kk = tid & 15, seg = tid >> 4;
+  const float2 *fb = frames + (long long)h0.frame * fl;
+  const int nb0 = h0.lag + 256 * (part * K4F_PAIRS);
+  const bool interior = (nb0 > 0) && (nb0 + 256 * K4F_PAIRS < fl);          // workgroup-uniform
+  float2 stage[4];
+  int nrow[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) nrow[r] = nb0 + 256 * min(16 * r + seg, K4F_PAIRS - 1) + kk;
+  auto load_chunk = [&](int c) {
+    if (interior) {
+#pragma unroll
+      for (int r = 0; r < 4; r++) stage[r] = fb[nrow[r] + 16 * c];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int n = nrow[r] + 16 * c;
+        const bool inr = (n > 0) && (n < fl);      // cc:205, sample 0 excluded
+        const float2 v = fb[min(max(n, 0), fl - 1)];
+        stage[r] = inr ? v : make_float2(0.0f, 0.0f);
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int pj = 16 * r + seg;
+      if (pj < K4F_PAIRS) *reinterpret_cast<float2 *>(&smp[pj * K4F_ROWDW + 2 * kk]) = stage[r];
+    }
+  };
+
+  float inp[NF], quad[NF];
+#pragma unroll
+  for (int q = 0; q < NF; q++) { inp[q] = 0.0f; quad[q] = 0.0f; }
+
+  if (tabled) {
+    // lanes 0..NF-1 of each wave own the recurrence of (frequency = lane, this wave's tone)
+    float cq = 1.0f, sq = 0.0f, cdq = 1.0f, sdq = 0.0f;
+    if (lane < NF) {
+      float fq = f0[0];
+#pragma unroll
+      for (int q = 1; q < NF; q++) fq = (lane == q) ? f0[q] : fq;
+      const float fp = (h0.m_type == UWSPR_LINEAR)
+                           ? (float)((double)fq + ((double)h0.drift / 2.0) * ((double)(float)0 - 81.0) / 81.0)
+                           : fq + h0.slmc;                                   // cc:173 / cc:179 (drift == 0)
+      double sn, cs;
+      sincos(kTwoPiDt * (double)(fp + delta), &sn, &cs);
+      cdq = (float)cs;
+      sdq = (float)sn;
+    }
+    load_chunk(0);
+    for (int ch = 0; ch < 16; ch++) {
+      __syncthreads();              // the previous chunk has been read by everyone
+      store_chunk();
+      if (lane < NF) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          tab[tone][k][lane] = make_float2(cq, sq);
+          const float nc = cq * cdq - sq * sdq;   // cc:193-195
+          const float ns = cq * sdq + sq * cdq;
+          cq = nc; sq = ns;
+        }
+      }
+      __syncthreads();
+      load_chunk(min(ch + 1, 15));  // in flight during the arithmetic (no branch around it)
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const float2 x = *reinterpret_cast<const float2 *>(&smp[row * K4F_ROWDW + 2 * k]);
+#pragma unroll
+        for (int q = 0; q < NF; q++) {
+          const float2 ph = tab[tone][k][q];     // same address in every lane: LDS broadcast
+          inp[q] = (inp[q] + x.x * ph.x) + x.y * ph.y;      // cc:206
+          quad[q] = (quad[q] - x.x * ph.y) + x.y * ph.x;    // cc:207
+        }
+      }
+    }
+  } else {
+    float c[NF], s[NF], cd[NF], sd[NF];
+#pragma unroll
+    for (int q = 0; q < NF; q++) {
+      const float fp = (float)((double)f0[q] +
+                               ((double)h0.drift / 2.0) * ((double)(float)own_i - 81.0) / 81.0);  // cc:173
+      double sn, cs;
+      sincos(kTwoPiDt * (double)(fp + delta), &sn, &cs);
+      cd[q] = (float)cs; sd[q] = (float)sn; c[q] = 1.0f; s[q] = 0.0f;
+    }
+    load_chunk(0);
+    for (int ch = 0; ch < 16; ch++) {
+      __syncthreads();
+      store_chunk();
+      __syncthreads();
+      load_chunk(min(ch + 1, 15));
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const float2 x = *reinterpret_cast<const float2 *>(&smp[row * K4F_ROWDW + 2 * k]);
+#pragma unroll
+        for (int q = 0; q < NF; q++) {
+          inp[q] = (inp[q] + x.x * c[q]) + x.y * s[q];      // cc:206
+          quad[q] = (quad[q] - x.x * s[q]) + x.y * c[q];    // cc:207
+          const float nc = c[q] * cd[q] - s[q] * sd[q];     // cc:193-195
+          const float ns = c[q] * sd[q] + s[q] * cd[q];
+          c[q] = nc; s[q] = ns;
+        }
+      }
+    }
+  }
+
+  if (mine) {
+#pragma unroll
+    for (int q = 0; q < NF; q++)
+      p_out[(((long long)slot * NF + q) * UWSPR_NSYM + own_i) * 4 + tone] =
+          ieee_sqrtf(inp[q] * inp[q] + quad[q] * quad[q]);   // cc:211
+  }
+}
+
+// hyps: nslots x 5 records; the 5 of a slot must share frame, lag, drift and model (S1 / S4)
+void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int nslots,
+                            int64_t nhyps, float4 *p) {
+  if (nslots <= 0) return;
+  prof_scope ps(c, UWSPR_K_TONECORR, nhyps);
+  hipLaunchKernelGGL(k4_fstage<5>, dim3(3u * (unsigned)nslots), dim3(256), 0, c->stream,
+                     (const float2 *)frames, c->fc.fl, B, hyps, nslots, (float *)p);
+}
+
+}  // namespace uwspr
+
+// ---------------------------------------------------------------------------
 // Grid form: the (freq, drift, lag) sweep around one centre per frame
 // (BASELINE configs[2]).  All hypotheses of a frame and symbol read the same
 // samples, and hypotheses that differ only in lag share their tone phasors, so:

@@ -106,6 +106,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   // back to one lane-set per hypothesis (k4_tonecorr) -- both are parity-tested
   c->use_lag_groups = !(getenv("UWSPR_K4_GROUPS") && atoi(getenv("UWSPR_K4_GROUPS")) == 0);
   c->use_lag_ring = !(getenv("UWSPR_K4_RING") && atoi(getenv("UWSPR_K4_RING")) == 0);
+  c->use_fstage = !(getenv("UWSPR_K4_FSTAGE") && atoi(getenv("UWSPR_K4_FSTAGE")) == 0);
   // frequency/drift stages through the grid form: parity-tested but measured 9 % SLOWER than the
   // flat kernel at 5 hypotheses per candidate (4 waves/SIMD, window loads not overlapped): opt-in
   c->use_stage_grid = getenv("UWSPR_K4_STAGE_GRID") && atoi(getenv("UWSPR_K4_STAGE_GRID")) != 0;
@@ -659,6 +660,7 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
       done = launch_tonecorr_stage_grid(c, dframes, B, (int)nslots, c->d_cent, c->d_cent_frame, 1, zero1,
                                         2, dd2, c->d_p);
     if (done) { /* launched */ }
+    else if (c->use_fstage && (s == 1 || s == 4)) launch_tonecorr_fstage(c, dframes, B, h, (int)nslots, H, c->d_p);
     else if (use_groups && s == 3 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)nslots, 5, 16, H, c->d_p);
     else if (use_groups && s == 5 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, 8, H, c->d_p);
     else if (use_groups && (s == 0 || s == 3)) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)nslots, 5, H, c->d_p);

@@ -133,6 +133,7 @@ struct uwspr_ctx {
   uwspr_candidate *cur_cands; int32_t *cur_npk; uwspr_demod_out *cur_dout;
   int last_per_frame;
   bool use_lag_groups, use_stage_grid;
+  bool use_fstage;       // S1/S4 through the frequency-stage form (UWSPR_K4_FSTAGE=0: flat kernel)
   bool use_lag_ring;     // S3/S5 groups through the LDS-ring form (UWSPR_K4_RING=0: plain groups)
   size_t cap_slab; uint8_t *d_slab;
 
@@ -155,6 +156,8 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
 // lag-group form: G groups, each instantiated for NL in {5, 6, 8} lags
 void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
                             int NL, int64_t nhyps, float4 *p);
+void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int nslots,
+                            int64_t nhyps, float4 *p);
 void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
                           int NL, int step, int64_t nhyps, float4 *p);
 // grid form (one centre per frame, shared sample windows); false = does not fit, use the flat path

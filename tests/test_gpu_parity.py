@@ -281,11 +281,12 @@ def test_schedule_without_lag_groups_is_identical(G, frames, vec, monkeypatch):
     cands = [vec["cands"][b, :int(vec["npk"][b])] for b in range(4)]
     per = max(len(c) for c in cands)
     outs = []
-    for groups, stage_grid, ring in (("1", "1", "1"), ("0", "0", "1"), ("1", "0", "0"), ("0", "1", "0"),
-                                     ("1", "0", "1")):
+    for groups, stage_grid, ring, fstage in (("1", "1", "1", "0"), ("0", "0", "1", "0"), ("1", "0", "0", "1"),
+                                             ("0", "1", "0", "0"), ("1", "0", "1", "1"), ("0", "0", "0", "1")):
         monkeypatch.setenv("UWSPR_K4_GROUPS", groups)        # lag sweeps: k4_group vs k4_tonecorr
         monkeypatch.setenv("UWSPR_K4_STAGE_GRID", stage_grid)  # freq/drift stages: k4_grid vs k4_tonecorr
         monkeypatch.setenv("UWSPR_K4_RING", ring)            # S3/S5 lag groups: k4_ring vs k4_group
+        monkeypatch.setenv("UWSPR_K4_FSTAGE", fstage)        # S1/S4: k4_fstage vs k4_tonecorr
         c = G.Context()
         try:
             outs.append(c.demod_batch(frames, cands, max_per_frame=per))
@@ -469,7 +470,11 @@ def test_schedule_at_the_frame_edges(ctx, G, oracle):
         assert len(c) >= 1
         extra = c[:1].copy()
         extra["shift"] = 0 if b < 2 else 3775 + 128              # S0 lags -128..128 / beyond the end
-        cands.append(np.concatenate([c, extra]))
+        drifting = c[:1].copy()                                   # a linear candidate WITH drift: per-symbol
+        drifting["m_type"] = 0                                    # frequencies (k4_fstage's general path)
+        raw = bytearray(drifting.tobytes()); raw[24:28] = np.float32(1.5).tobytes()
+        drifting = np.frombuffer(bytes(raw), c.dtype).copy()
+        cands.append(np.concatenate([c, extra, drifting]))
     per = max(len(c) for c in cands)
     out = ctx.demod_batch(frames, cands, max_per_frame=per)
     worth = 0
