@@ -9,7 +9,7 @@ import os
 import sys
 from collections import defaultdict
 
-PIPELINE_GRIDS = {"165888", "497664", "331776", "829440"}   # the 6 K4 launches of a 256-frame step
+PIPELINE_GRIDS = {"165888", "497664", "331776", "829440", "196608"}   # the 6 K4 launches of a 256-frame step
 
 
 def per_step(d, counter):
@@ -35,7 +35,7 @@ def main():
     fetch = fetch_kb * 1024 * 2
     write = write_kb * 1024
     out = {
-        "kernel_family": "k4 (k4_group<5>, k4_tonecorr<1> x3, k4_ring<5,16>, k4_ring<6,8>): the 6 launches of one bench step",
+        "kernel_family": "k4 (S0 k4_group<5>, S1/S4 k4_fstage<5>, S2 k4_tonecorr<1>, S3 k4_ring<5,16>, S5 k4_ring<6,8>): the 6 launches of one bench step",
         "bytes_per_launch": (fetch + write) / 6.0,
         "fetch_bytes_per_step_corrected": fetch,
         "write_bytes_per_step": write,
