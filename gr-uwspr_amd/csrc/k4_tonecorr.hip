@@ -33,6 +33,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "uwspr_internal.h"
 
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
   const bool okA = A.frame >= 0 && A.frame < nframes;
   const bool okB = (gA + 1 < G) && Bg.frame >= 0 && Bg.frame < nframes;
   const int frA = okA ? A.frame : 0, frB = okB ? Bg.frame : 0;
-  const int nvA = okA ? A.nvalid : 0, nvB = okB ? Bg.nvalid : 0;
+  const int nvA = okA ? (A.nvalid & 0xff) : 0, nvB = okB ? (Bg.nvalid & 0xff) : 0;   // bit 8: see k4_ring
   // lag of slot l for the two groups; skipped groups / unused slots point at safe samples
   int la[NL], lb[NL];
 #pragma unroll
@@ -425,8 +426,8 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
     }
     // groups that are skipped produce zeros for their hypotheses
     const dev_grp &gy = mineA ? A : Bg;
-    if (!(mineA ? okA : okB) && gy.nvalid > 0)
-      for (int l = 0; l < gy.nvalid && l < NL; l++)
+    if (!(mineA ? okA : okB) && (gy.nvalid & 0xff) > 0)
+      for (int l = 0; l < (gy.nvalid & 0xff) && l < NL; l++)
         p_out[((long long)(gy.hyp_base + (int)((gy.hmap >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
   }
 }
@@ -486,7 +487,11 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   const bool okA = A.frame >= 0 && A.frame < nframes;
   const bool okB = (gA + 1 < G) && Bg.frame >= 0 && Bg.frame < nframes;
   const int frA = okA ? A.frame : 0, frB = okB ? Bg.frame : 0;
-  const int nvA = okA ? A.nvalid : 0, nvB = okB ? Bg.nvalid : 0;
+  const int nvA = okA ? (A.nvalid & 0xff) : 0, nvB = okB ? (Bg.nvalid & 0xff) : 0;
+  // nvalid bit 8: lag slot 2 repeats the previous stage's winner, its metric is known and nobody
+  // reads its p[] -- skipped when that holds for every live group of the wave (NL == 5 only)
+  const bool knownA = !okA || (A.nvalid & 0x100) != 0, knownB = !okB || (Bg.nvalid & 0x100) != 0;
+  const bool skip_mid = (NL == 5) && knownA && (knownB || sb >= PPW);
   // first lag of the two groups; skipped groups point at safe samples
   const int l0A = okA ? A.lag[0] : 1 - 256 * iA0;
   const int l0B = okB ? Bg.lag[0] : 1;
@@ -569,46 +574,53 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   for (int l = 0; l < NL; l++) { inp[l] = 0.0f; quad[l] = 0.0f; }
 
   int wpos = 0;  // ring position that slot c + Q + 1 will overwrite (= position of slot c)
-  for (int ch = 0; ch < 16; ch++) {
-    // in flight during the chunk's arithmetic (the last chunk re-fetches the last slot: no
-    // branch here or after the arithmetic, or the compiler sinks the arithmetic past it)
-    load_slot(min(ch + Q + 1, NSLOT - 1));
-    wave_lds_fence();                      // the slots written so far are visible
-    float2 xc[NL], xn[NL];
-#pragma unroll
-    for (int l = 0; l < NL; l++) {
-      xc[l] = *reinterpret_cast<const float2 *>(&lds[sa[(STEP * l) >> 4] + 2 * ((STEP * l) & 15)]);
-    }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      if (k < 15) {
-#pragma unroll
-        for (int l = 0; l < NL; l++) {
-          const int o = k + 1 + STEP * l;
-          xn[l] = *reinterpret_cast<const float2 *>(&lds[sa[o >> 4] + 2 * (o & 15)]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep the reads of step k+1 ahead of step k's arithmetic
+  auto walk = [&](auto skip_tag) {
+    constexpr bool SKIP = decltype(skip_tag)::value;   // leave lag slot 2 out
+    for (int ch = 0; ch < 16; ch++) {
+      // in flight during the chunk's arithmetic (the last chunk re-fetches the last slot: no
+      // branch here or after the arithmetic, or the compiler sinks the arithmetic past it)
+      load_slot(min(ch + Q + 1, NSLOT - 1));
+      wave_lds_fence();                      // the slots written so far are visible
+      float2 xc[NL], xn[NL];
 #pragma unroll
       for (int l = 0; l < NL; l++) {
-        inp[l] = (inp[l] + xc[l].x * c) + xc[l].y * s;     // cc:206
-        quad[l] = (quad[l] - xc[l].x * s) + xc[l].y * c;   // cc:207
+        if (SKIP && l == 2) { xc[l] = make_float2(0.0f, 0.0f); xn[l] = xc[l]; continue; }
+        xc[l] = *reinterpret_cast<const float2 *>(&lds[sa[(STEP * l) >> 4] + 2 * ((STEP * l) & 15)]);
       }
-      const float nc = c * cd - s * sd;                    // cc:193-195
-      const float ns = c * sd + s * cd;
-      c = nc; s = ns;
 #pragma unroll
-      for (int l = 0; l < NL; l++) xc[l] = xn[l];
+      for (int k = 0; k < 16; k++) {
+        if (k < 15) {
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            if (SKIP && l == 2) continue;
+            const int o = k + 1 + STEP * l;
+            xn[l] = *reinterpret_cast<const float2 *>(&lds[sa[o >> 4] + 2 * (o & 15)]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads of step k+1 ahead of step k's arithmetic
+#pragma unroll
+        for (int l = 0; l < NL; l++) {
+          if (SKIP && l == 2) continue;
+          inp[l] = (inp[l] + xc[l].x * c) + xc[l].y * s;     // cc:206
+          quad[l] = (quad[l] - xc[l].x * s) + xc[l].y * c;   // cc:207
+        }
+        const float nc = c * cd - s * sd;                    // cc:193-195
+        const float ns = c * sd + s * cd;
+        c = nc; s = ns;
+#pragma unroll
+        for (int l = 0; l < NL; l++) xc[l] = xn[l];
+      }
+      // slot ch is finished with: its position takes slot ch + Q + 1, and the addresses rotate
+      wave_lds_fence();
+      store_slot(wpos);
+      wpos = (wpos + 1 == M) ? 0 : wpos + 1;
+      const int first = sa[0];
+#pragma unroll
+      for (int q = 0; q + 1 < M; q++) sa[q] = sa[q + 1];
+      sa[M - 1] = first;
     }
-    // slot ch is finished with: its position takes slot ch + Q + 1, and the addresses rotate
-    wave_lds_fence();
-    store_slot(wpos);
-    wpos = (wpos + 1 == M) ? 0 : wpos + 1;
-    const int first = sa[0];
-#pragma unroll
-    for (int q = 0; q + 1 < M; q++) sa[q] = sa[q + 1];
-    sa[M - 1] = first;
-  }
+  };
+  if (skip_mid) walk(std::true_type{}); else walk(std::false_type{});
 
   if (g0 + pr < total) {
     const int nv = mineA ? nvA : nvB;
@@ -616,15 +628,15 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
     const uint32_t hm = mineA ? A.hmap : Bg.hmap;
 #pragma unroll
     for (int l = 0; l < NL; l++) {
-      if (l < nv) {
+      if (l < nv && !(skip_mid && l == 2)) {
         const float pj = ieee_sqrtf(inp[l] * inp[l] + quad[l] * quad[l]);  // cc:211
         p_out[((long long)(hb + (int)((hm >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = pj;
       }
     }
     // groups that are skipped produce zeros for their hypotheses
     const dev_grp &gy = mineA ? A : Bg;
-    if (!(mineA ? okA : okB) && gy.nvalid > 0)
-      for (int l = 0; l < gy.nvalid && l < NL; l++)
+    if (!(mineA ? okA : okB) && (gy.nvalid & 0xff) > 0)
+      for (int l = 0; l < (gy.nvalid & 0xff) && l < NL; l++)
         p_out[((long long)(gy.hyp_base + (int)((gy.hmap >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
   }
 }
@@ -698,6 +710,9 @@ __global__ __launch_bounds__(256) void k4_fstage(
     return;
   }
   const bool tabled = (h0.m_type != UWSPR_LINEAR) || (h0.drift == 0.0f);   // fp independent of the symbol
+  // the middle frequency repeats the previous stage's winner when marked (frame <= -2): nobody
+  // reads its p[], so it is left out
+  const bool skip_mid = hyps[(size_t)slot * NF + NF / 2].frame <= -2;
   const float delta = ((float)tone - 1.5f) * 1.46484375f;                    // cc:148
 
   // ---- loader: round r of a chunk = symbol 16 r + tid/16, sample tid%16 ----
@@ -751,31 +766,36 @@ __global__ __launch_bounds__(256) void k4_fstage(
       sdq = (float)sn;
     }
     load_chunk(0);
-    for (int ch = 0; ch < 16; ch++) {
-      __syncthreads();              // the previous chunk has been read by everyone
-      store_chunk();
-      if (lane < NF) {
+    auto walk = [&](auto skip_tag) {
+      constexpr bool SKIP = decltype(skip_tag)::value;
+      for (int ch = 0; ch < 16; ch++) {
+        __syncthreads();              // the previous chunk has been read by everyone
+        store_chunk();
+        if (lane < NF) {
+#pragma unroll
+          for (int k = 0; k < 16; k++) {
+            tab[tone][k][lane] = make_float2(cq, sq);
+            const float nc = cq * cdq - sq * sdq;   // cc:193-195
+            const float ns = cq * sdq + sq * cdq;
+            cq = nc; sq = ns;
+          }
+        }
+        __syncthreads();
+        load_chunk(min(ch + 1, 15));  // in flight during the arithmetic (no branch around it)
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-          tab[tone][k][lane] = make_float2(cq, sq);
-          const float nc = cq * cdq - sq * sdq;   // cc:193-195
-          const float ns = cq * sdq + sq * cdq;
-          cq = nc; sq = ns;
+          const float2 x = *reinterpret_cast<const float2 *>(&smp[row * K4F_ROWDW + 2 * k]);
+#pragma unroll
+          for (int q = 0; q < NF; q++) {
+            if (SKIP && q == NF / 2) continue;
+            const float2 ph = tab[tone][k][q];     // same address in every lane: LDS broadcast
+            inp[q] = (inp[q] + x.x * ph.x) + x.y * ph.y;      // cc:206
+            quad[q] = (quad[q] - x.x * ph.y) + x.y * ph.x;    // cc:207
+          }
         }
       }
-      __syncthreads();
-      load_chunk(min(ch + 1, 15));  // in flight during the arithmetic (no branch around it)
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const float2 x = *reinterpret_cast<const float2 *>(&smp[row * K4F_ROWDW + 2 * k]);
-#pragma unroll
-        for (int q = 0; q < NF; q++) {
-          const float2 ph = tab[tone][k][q];     // same address in every lane: LDS broadcast
-          inp[q] = (inp[q] + x.x * ph.x) + x.y * ph.y;      // cc:206
-          quad[q] = (quad[q] - x.x * ph.y) + x.y * ph.x;    // cc:207
-        }
-      }
-    }
+    };
+    if (skip_mid) walk(std::true_type{}); else walk(std::false_type{});
   } else {
     float c[NF], s[NF], cd[NF], sd[NF];
 #pragma unroll
@@ -810,8 +830,9 @@ __global__ __launch_bounds__(256) void k4_fstage(
   if (mine) {
 #pragma unroll
     for (int q = 0; q < NF; q++)
-      p_out[(((long long)slot * NF + q) * UWSPR_NSYM + own_i) * 4 + tone] =
-          ieee_sqrtf(inp[q] * inp[q] + quad[q] * quad[q]);   // cc:211
+      if (!(skip_mid && q == NF / 2))
+        p_out[(((long long)slot * NF + q) * UWSPR_NSYM + own_i) * 4 + tone] =
+            ieee_sqrtf(inp[q] * inp[q] + quad[q] * quad[q]);   // cc:211
   }
 }
 

@@ -220,9 +220,11 @@ void launch_prep_hyps(uwspr_ctx *c, const uwspr_hyp *abi, dev_hyp *out, int H) {
 // emits the next ones; hypotheses per candidate: S0 5, S1 5, S2 2, S3 5, S4 5,
 // S5 17 (cc:409-482).  One thread per candidate slot.
 
+// known: the hypothesis repeats the previous stage's winner -- frame <= -2 tells K4 and the
+// fold to leave it alone (its metric is cand_state::csync)
 __device__ inline void emit(dev_hyp *h, const cand_state &st, bool on, int lag, float f0,
-                            float drift) {
-  h->frame = on ? st.frame : -1;
+                            float drift, bool known = false) {
+  h->frame = on ? (known ? -2 - st.frame : st.frame) : -1;
   h->lag = lag; h->f0 = f0; h->drift = drift; h->slmc = st.slmc; h->m_type = st.m_type;
 }
 
@@ -279,7 +281,7 @@ __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
     st.frame = -1; st.m_type = 0; st.slmc = 0.0f; st.f1 = 0.0f; st.drift1 = 0.0f;
     st.shift1 = 0; st.sync1 = 0.0f;
   }
-  st.worth = 0; st.driftp = 0.0f; st.driftm = 0.0f;
+  st.worth = 0; st.driftp = 0.0f; st.driftm = 0.0f; st.csync = 0.0f; st.cknown = 0;
   state[slot] = st;
   // S0 (cc:409-415): mode 0, lag = shift1-128 .. shift1+128 step 64, f0 = f1 + 0*0.0f
   dev_hyp *h = hyps + (size_t)slot * 5;
@@ -299,7 +301,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
                                                 dev_hyp *__restrict__ hout,
                                                 dev_grp *__restrict__ grps,
                                                 uwspr_candidate *__restrict__ cent,
-                                                int32_t *__restrict__ cframe) {
+                                                int32_t *__restrict__ cframe, bool reuse) {
   cand_state st = state[slot];
   const bool live = st.frame >= 0;
   constexpr int NIN = STAGE == 1 ? 5 : STAGE == 2 ? 5 : STAGE == 3 ? 2 : STAGE == 4 ? 5 : 5;
@@ -311,12 +313,17 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
   if (STAGE == 1) {
     // after S0 (mode 0) -> S1 (cc:416-419): mode 1, f = f1 + ifreq*0.25, lag = shift1
     if (live) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
+    // q = 2 is (f1 + 0, shift1, drift1): the S0 hypothesis that just won (if one did)
+    st.cknown = (reuse && live && st.sync1 > -1e30f) ? 1 : 0;
+    st.csync = st.sync1;
     for (int q = 0; q < 5; q++)
-      emit(&ho[q], st, live, st.shift1, st.f1 + (float)(q - 2) * 0.25f, st.drift1);
+      emit(&ho[q], st, live, st.shift1, st.f1 + (float)(q - 2) * 0.25f, st.drift1, q == 2 && st.cknown);
     emit_centre(&cent[slot], &cframe[slot], st, live);
   } else if (STAGE == 2) {
     // after S1 -> S2 (cc:423-433): linear only, drift1 +- 0.5 at (f1, shift1)
     if (live) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
+    st.cknown = (reuse && live && st.sync1 > -1e30f) ? 1 : 0;   // (f1, shift1, drift1) has metric sync1
+    st.csync = st.sync1;
     const bool lin = live && st.m_type == UWSPR_LINEAR;
     st.driftp = (float)((double)st.drift1 + 0.5);
     st.driftm = (float)((double)st.drift1 - 0.5);
@@ -330,24 +337,30 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
       // each mode-1 call writes *f1/*shift1 back (cc:236-237): unchanged unless
       // its metric failed to beat -1e30 (NaN), where the defaults 0 / 0.0 land
       float syncp = -1e30f, syncm = -1e30f;
-      if (sy[0] > syncp) syncp = sy[0]; else { st.f1 = 0.0f; st.shift1 = 0; }
-      if (sy[1] > syncm) syncm = sy[1]; else { st.f1 = 0.0f; st.shift1 = 0; }
+      if (sy[0] > syncp) syncp = sy[0]; else { st.f1 = 0.0f; st.shift1 = 0; st.cknown = 0; }
+      if (sy[1] > syncm) syncm = sy[1]; else { st.f1 = 0.0f; st.shift1 = 0; st.cknown = 0; }
       if (syncp > st.sync1) { st.drift1 = st.driftp; st.sync1 = syncp; }
       else if (syncm > st.sync1) { st.drift1 = st.driftm; st.sync1 = syncm; }
     }
     st.worth = (live && st.sync1 > 0.10f) ? 1 : 0;
+    // q = 2 is (f1, shift1, drift1): the winner of S1, or of S2 when a drift try beat it
+    st.csync = st.sync1;
     const float f0 = st.f1 + (float)0 * 0.0f;
     int lags[5];
     for (int q = 0; q < 5; q++) {
       lags[q] = st.shift1 - 32 + 16 * q;
-      emit(&ho[q], st, st.worth != 0, lags[q], f0, st.drift1);
+      emit(&ho[q], st, st.worth != 0, lags[q], f0, st.drift1, q == 2 && st.cknown);
     }
     emit_group(&grps[slot], st, st.worth != 0, f0, st.drift1, slot * 5, lags, 5);
+    if (st.cknown) grps[slot].nvalid |= 0x100;   // lag slot 2 is known: K4 skips it
   } else if (STAGE == 4) {
     // after S3 -> S4 (cc:449-452): f = f1 + ifreq*0.05
     if (st.worth) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
+    st.cknown = (reuse && st.worth && st.sync1 > -1e30f) ? 1 : 0;   // q = 2 repeats the S3 winner
+    st.csync = st.sync1;
     for (int q = 0; q < 5; q++)
-      emit(&ho[q], st, st.worth != 0, st.shift1, st.f1 + (float)(q - 2) * 0.05f, st.drift1);
+      emit(&ho[q], st, st.worth != 0, st.shift1, st.f1 + (float)(q - 2) * 0.05f, st.drift1,
+           q == 2 && st.cknown);
     emit_centre(&cent[slot], &cframe[slot], st, st.worth != 0);
   } else {
     // after S4 -> S5 (cc:457-468): 17 jiggered shifts, mode 2
@@ -388,17 +401,20 @@ template <int STAGE>
 __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__restrict__ hin,
                              const float4 *__restrict__ p, float *__restrict__ sync,
                              dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
-                             uwspr_candidate *__restrict__ cent, int32_t *__restrict__ cframe, int nslots) {
+                             uwspr_candidate *__restrict__ cent, int32_t *__restrict__ cframe, int nslots,
+                             int reuse) {
   constexpr int NIN = STAGE == 3 ? 2 : 5;
   __shared__ k5_wave_lds L[NIN];
   __shared__ float sy[NIN];
   const int slot = blockIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = slot * NIN + wv;
-  const float s = fold_wave<false>(hin, p, h, 50.0f, nullptr, L[wv], nullptr);
+  // a hypothesis marked known (frame <= -2) repeats the previous winner: its metric is in the state
+  const float s = (hin[h].frame <= -2) ? state[slot].csync
+                                       : fold_wave<false>(hin, p, h, 50.0f, nullptr, L[wv], nullptr);
   if ((threadIdx.x & 63) == 0) { sy[wv] = s; sync[h] = s; }
   __syncthreads();
-  if (threadIdx.x == 0) sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe);
+  if (threadIdx.x == 0) sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0);
 }
 
 // out[slot]: state + per-try sync / rms / shift / symbols (cc:465-475)
@@ -482,11 +498,11 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots) {
   dev_hyp *hout = (stage & 1) ? half1 : half0;
   dim3 g(nslots);
   switch (stage) {
-    case 1: hipLaunchKernelGGL(k5_fold_step<1>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots); break;
-    case 2: hipLaunchKernelGGL(k5_fold_step<2>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots); break;
-    case 3: hipLaunchKernelGGL(k5_fold_step<3>, g, dim3(128), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots); break;
-    case 4: hipLaunchKernelGGL(k5_fold_step<4>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots); break;
-    default: hipLaunchKernelGGL(k5_fold_step<5>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots); break;
+    case 1: hipLaunchKernelGGL(k5_fold_step<1>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0); break;
+    case 2: hipLaunchKernelGGL(k5_fold_step<2>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0); break;
+    case 3: hipLaunchKernelGGL(k5_fold_step<3>, g, dim3(128), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0); break;
+    case 4: hipLaunchKernelGGL(k5_fold_step<4>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0); break;
+    default: hipLaunchKernelGGL(k5_fold_step<5>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0); break;
   }
 }
 

@@ -107,6 +107,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->use_lag_groups = !(getenv("UWSPR_K4_GROUPS") && atoi(getenv("UWSPR_K4_GROUPS")) == 0);
   c->use_lag_ring = !(getenv("UWSPR_K4_RING") && atoi(getenv("UWSPR_K4_RING")) == 0);
   c->use_fstage = !(getenv("UWSPR_K4_FSTAGE") && atoi(getenv("UWSPR_K4_FSTAGE")) == 0);
+  c->reuse_centre = !(getenv("UWSPR_K4_REUSE") && atoi(getenv("UWSPR_K4_REUSE")) == 0);
   // frequency/drift stages through the grid form: parity-tested but measured 9 % SLOWER than the
   // flat kernel at 5 hypotheses per candidate (4 waves/SIMD, window loads not overlapped): opt-in
   c->use_stage_grid = getenv("UWSPR_K4_STAGE_GRID") && atoi(getenv("UWSPR_K4_STAGE_GRID")) != 0;

@@ -72,6 +72,10 @@ struct cand_state {
   int32_t shift1;
   int32_t worth;
   float driftp, driftm;
+  // The middle hypothesis of S1, S3 and S4 is the hypothesis that won the stage before it
+  // (same f0, lag, drift): its metric is already known and K4 / the fold skip it.
+  float csync;         // metric of (f1, shift1, drift1) when cknown
+  int32_t cknown;
 };
 
 struct fdr_consts {
@@ -134,6 +138,7 @@ struct uwspr_ctx {
   int last_per_frame;
   bool use_lag_groups, use_stage_grid;
   bool use_fstage;       // S1/S4 through the frequency-stage form (UWSPR_K4_FSTAGE=0: flat kernel)
+  bool reuse_centre;     // skip the stage-winner hypothesis in S1/S3/S4 (UWSPR_K4_REUSE=0: recompute it)
   bool use_lag_ring;     // S3/S5 groups through the LDS-ring form (UWSPR_K4_RING=0: plain groups)
   size_t cap_slab; uint8_t *d_slab;
 

@@ -281,12 +281,15 @@ def test_schedule_without_lag_groups_is_identical(G, frames, vec, monkeypatch):
     cands = [vec["cands"][b, :int(vec["npk"][b])] for b in range(4)]
     per = max(len(c) for c in cands)
     outs = []
-    for groups, stage_grid, ring, fstage in (("1", "1", "1", "0"), ("0", "0", "1", "0"), ("1", "0", "0", "1"),
-                                             ("0", "1", "0", "0"), ("1", "0", "1", "1"), ("0", "0", "0", "1")):
+    for groups, stage_grid, ring, fstage, reuse in (
+            ("1", "1", "1", "0", "1"), ("0", "0", "1", "0", "0"), ("1", "0", "0", "1", "1"),
+            ("0", "1", "0", "0", "0"), ("1", "0", "1", "1", "1"), ("0", "0", "0", "1", "0"),
+            ("1", "0", "1", "1", "0"), ("0", "0", "0", "0", "1")):
         monkeypatch.setenv("UWSPR_K4_GROUPS", groups)        # lag sweeps: k4_group vs k4_tonecorr
         monkeypatch.setenv("UWSPR_K4_STAGE_GRID", stage_grid)  # freq/drift stages: k4_grid vs k4_tonecorr
         monkeypatch.setenv("UWSPR_K4_RING", ring)            # S3/S5 lag groups: k4_ring vs k4_group
         monkeypatch.setenv("UWSPR_K4_FSTAGE", fstage)        # S1/S4: k4_fstage vs k4_tonecorr
+        monkeypatch.setenv("UWSPR_K4_REUSE", reuse)          # stage-winner hypothesis skipped vs recomputed
         c = G.Context()
         try:
             outs.append(c.demod_batch(frames, cands, max_per_frame=per))
