@@ -13,5 +13,5 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $OUT/bench_write.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/pmc_sq -- python3 bench.py --steps 3 --warmup 1 --no-cpu > $OUT/bench_sq.log 2>&1
 timeout -k 10 120 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/calib_fetch -- /tmp/fetch_calib > $OUT/calib.log 2>&1
-timeout -k 10 300 python3 bench.py --steps 20 --warmup 3 > $OUT/bench_plain.log 2>&1
+timeout -k 10 300 python3 bench.py > $OUT/bench_plain.log 2>&1
 echo done
