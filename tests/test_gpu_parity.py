@@ -495,3 +495,29 @@ def test_schedule_at_the_frame_edges(ctx, G, oracle):
                 assert o["jig_sync"].tobytes() == d["jig_sync"].tobytes()
     assert worth >= 4
     assert min(int(out[b, j]["shift1"]) for b in range(2) for j in range(len(cands[b]))) < 64
+
+
+def test_schedule_on_a_silent_frame(ctx, G, oracle):
+    """All-zero samples: every metric is 0/0 = NaN, no hypothesis ever beats the -1e30
+    default (cc:227-231), the reference's 0 / 0.0 defaults land in the state and the
+    candidate is not worth a try.  Also the path on which stage-winner reuse must stay off."""
+    frames = np.zeros((2, 45000, 2), np.float32)
+    frames[1] = G.synth.make_frames(1, seed=5, snr_db=-15.0)[0]      # a normal frame beside it
+    fdr = oracle.FDR()
+    real = fdr.transform(frames[1])[:1]
+    ghost = real.copy()                                              # same parameters on the silent frame
+    nl = real.copy()
+    nl["m_type"] = 1; nl["V1"] = -1.0; nl["V2"] = 2.0; nl["p1"] = 0; nl["p2"] = 450
+    cands = [np.concatenate([ghost, nl]), np.concatenate([real, nl])]
+    out = ctx.demod_batch(frames, cands, max_per_frame=2)
+    for b in range(2):
+        for j in range(2):
+            d = oracle.demod_candidate(cands[b][j], 1500, frames[b])
+            o = out[b, j]
+            assert int(o["worth_a_try"]) == d["worth_a_try"], (b, j)
+            assert int(o["shift1"]) == d["shift1"], (b, j)
+            for k in ("f1", "drift1", "sync1"):
+                assert np.float32(o[k]).tobytes() == np.float32(d[k]).tobytes(), (b, j, k)
+            if d["worth_a_try"]:
+                assert (o["symbols"] == d["symbols"]).all()
+    assert int(out[0, 0]["worth_a_try"]) == 0 and int(out[1, 0]["worth_a_try"]) == 1
