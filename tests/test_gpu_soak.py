@@ -11,9 +11,10 @@ from conftest import ROOT
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,hbw", [(140, 10), (42, 60)])
-def test_soak(n, hbw):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_parity.py"), str(n), str(hbw)],
+@pytest.mark.parametrize("n,hbw,maxdrift", [(140, 10, 0), (42, 60, 0), (84, 10, 3)])
+def test_soak(n, hbw, maxdrift):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_parity.py"), str(n), str(hbw),
+                        str(maxdrift)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
