@@ -212,7 +212,7 @@ static int k4_choose_t(long long pairs) {
 void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int H,
                      float4 *p) {
   if (H <= 0) return;
-  prof_scope ps(c, UWSPR_K_TONECORR, H);
+  prof_scope ps(c, UWSPR_K_TONECORR, H, true);
   const long long total = (long long)H * UWSPR_NSYM;
   const int T = k4_choose_t(total);
   const long long waves = (total + 16 * T - 1) / (16 * T);
@@ -220,9 +220,9 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   dim3 blk(64 * K4_WAVES);
-  if (T == 1) hipLaunchKernelGGL(k4_tonecorr<1>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, hyps, H, po);
-  else if (T == 2) hipLaunchKernelGGL(k4_tonecorr<2>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, hyps, H, po);
-  else hipLaunchKernelGGL(k4_tonecorr<4>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, hyps, H, po);
+  if (T == 1) launch_timed(c, ps, k4_tonecorr<1>, dim3(blocks), blk, 0, fr, c->fc.fl, B, hyps, H, po);
+  else if (T == 2) launch_timed(c, ps, k4_tonecorr<2>, dim3(blocks), blk, 0, fr, c->fc.fl, B, hyps, H, po);
+  else launch_timed(c, ps, k4_tonecorr<4>, dim3(blocks), blk, 0, fr, c->fc.fl, B, hyps, H, po);
 }
 
 }  // namespace uwspr
@@ -435,16 +435,16 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
 void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
                             int NL, int64_t nhyps, float4 *p) {
   if (G <= 0) return;
-  prof_scope ps(c, UWSPR_K_TONECORR, nhyps);
+  prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
   const long long total = (long long)G * UWSPR_NSYM;
   const long long waves = (total + 15) / 16;
   const unsigned blocks = (unsigned)((waves + K4G_WAVES - 1) / K4G_WAVES);
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   dim3 blk(64 * K4G_WAVES);
-  if (NL == 5) hipLaunchKernelGGL(k4_group<5>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, grps, G, po);
-  else if (NL == 6) hipLaunchKernelGGL(k4_group<6>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, grps, G, po);
-  else hipLaunchKernelGGL(k4_group<8>, dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, grps, G, po);
+  if (NL == 5) launch_timed(c, ps, k4_group<5>, dim3(blocks), blk, 0, fr, c->fc.fl, B, grps, G, po);
+  else if (NL == 6) launch_timed(c, ps, k4_group<6>, dim3(blocks), blk, 0, fr, c->fc.fl, B, grps, G, po);
+  else launch_timed(c, ps, k4_group<8>, dim3(blocks), blk, 0, fr, c->fc.fl, B, grps, G, po);
 }
 
 // ---------------------------------------------------------------------------
@@ -645,16 +645,20 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
 void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
                           int NL, int step, int64_t nhyps, float4 *p) {
   if (G <= 0) return;
-  prof_scope ps(c, UWSPR_K_TONECORR, nhyps);
+  const bool r5 = NL == 5 && step == 16, r6 = NL == 6 && step == 8;
+  if (!r5 && !r6) {   // no ring instance for this spacing: plain lag groups
+    launch_tonecorr_groups(c, frames, B, grps, G, NL <= 5 ? 5 : NL == 6 ? 6 : 8, nhyps, p);
+    return;
+  }
+  prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
   const long long total = (long long)G * UWSPR_NSYM;
   const long long waves = (total + 15) / 16;
   const unsigned blocks = (unsigned)((waves + K4G_WAVES - 1) / K4G_WAVES);
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   dim3 blk(64 * K4G_WAVES);
-  if (NL == 5 && step == 16) hipLaunchKernelGGL((k4_ring<5, 16>), dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, grps, G, po);
-  else if (NL == 6 && step == 8) hipLaunchKernelGGL((k4_ring<6, 8>), dim3(blocks), blk, 0, c->stream, fr, c->fc.fl, B, grps, G, po);
-  else launch_tonecorr_groups(c, frames, B, grps, G, NL <= 5 ? 5 : NL == 6 ? 6 : 8, nhyps, p);
+  if (r5) launch_timed(c, ps, (k4_ring<5, 16>), dim3(blocks), blk, 0, fr, c->fc.fl, B, grps, G, po);
+  else launch_timed(c, ps, (k4_ring<6, 8>), dim3(blocks), blk, 0, fr, c->fc.fl, B, grps, G, po);
 }
 
 
@@ -840,9 +844,9 @@ __global__ __launch_bounds__(256) void k4_fstage(
 void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int nslots,
                             int64_t nhyps, float4 *p) {
   if (nslots <= 0) return;
-  prof_scope ps(c, UWSPR_K_TONECORR, nhyps);
-  hipLaunchKernelGGL(k4_fstage<5>, dim3(3u * (unsigned)nslots), dim3(256), 0, c->stream,
-                     (const float2 *)frames, c->fc.fl, B, hyps, nslots, (float *)p);
+  prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
+  launch_timed(c, ps, k4_fstage<5>, dim3(3u * (unsigned)nslots), dim3(256), 0,
+               (const float2 *)frames, c->fc.fl, B, hyps, nslots, (float *)p);
 }
 
 }  // namespace uwspr
@@ -1003,14 +1007,14 @@ __global__ void k_grid_hyps(const uwspr_candidate *__restrict__ centres, grid_ar
 }
 
 template <int NL>
-static void launch_grid_t(uwspr_ctx *c, const float2 *fr, int nframes, int ncentres,
+static void launch_grid_t(uwspr_ctx *c, prof_scope &ps, const float2 *fr, int nframes, int ncentres,
                           const uwspr_candidate *centres, const int32_t *cframe, const grid_args &ga,
                           int wpw, float *po) {
   const int npairs = UWSPR_NSYM * ga.ncombo;
   const int waves = (npairs + 15) / 16;
   dim3 grid((waves + wpw - 1) / wpw, ncentres);
   const size_t lds = (size_t)wpw * ga.wmax * ga.wstride * sizeof(float2);
-  hipLaunchKernelGGL(k4_grid<NL>, grid, dim3(64 * wpw), lds, c->stream, fr, c->fc.fl, nframes, centres,
+  launch_timed(c, ps, k4_grid<NL>, grid, dim3(64 * wpw), lds, fr, c->fc.fl, nframes, centres,
                      cframe, ga, (float)c->p.cf, po);
 }
 
@@ -1033,17 +1037,17 @@ bool launch_grid_block(uwspr_ctx *c, const float *frames, int nframes, int ncent
   for (int l = 0; l < 8; l++) ga.off[l] = dlag[std::min(l, nv - 1)] - lo;
   const int wpw = grid_waves_per_wg(ga);
   if (wpw == 0) return false;
-  prof_scope ps(c, UWSPR_K_TONECORR, units);
+  prof_scope ps(c, UWSPR_K_TONECORR, units, true);
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   const int NL = nv <= 1 ? 1 : nv <= 2 ? 2 : nv <= 4 ? 4 : nv <= 5 ? 5 : nv <= 6 ? 6 : 8;
   switch (NL) {
-    case 1: launch_grid_t<1>(c, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
-    case 2: launch_grid_t<2>(c, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
-    case 4: launch_grid_t<4>(c, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
-    case 5: launch_grid_t<5>(c, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
-    case 6: launch_grid_t<6>(c, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
-    default: launch_grid_t<8>(c, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
+    case 1: launch_grid_t<1>(c, ps, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
+    case 2: launch_grid_t<2>(c, ps, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
+    case 4: launch_grid_t<4>(c, ps, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
+    case 5: launch_grid_t<5>(c, ps, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
+    case 6: launch_grid_t<6>(c, ps, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
+    default: launch_grid_t<8>(c, ps, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
   }
   return true;
 }

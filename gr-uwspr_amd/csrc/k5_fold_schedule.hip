@@ -301,7 +301,9 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
                                                 dev_hyp *__restrict__ hout,
                                                 dev_grp *__restrict__ grps,
                                                 uwspr_candidate *__restrict__ cent,
-                                                int32_t *__restrict__ cframe, bool reuse) {
+                                                int32_t *__restrict__ cframe, bool reuse, int team = 0) {
+  // team (stage 5 only): lanes 0..19 of the first wavefront all derive the same new state, in
+  // lockstep, and share the emission -- lane t < 17 writes try t, lanes 17..19 the lag groups
   cand_state st = state[slot];
   const bool live = st.frame >= 0;
   constexpr int NIN = STAGE == 1 ? 5 : STAGE == 2 ? 5 : STAGE == 3 ? 2 : STAGE == 4 ? 5 : 5;
@@ -365,18 +367,18 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
   } else {
     // after S4 -> S5 (cc:457-468): 17 jiggered shifts, mode 2
     if (st.worth) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
-    int lags[18];
-    for (int idt = 0; idt < UWSPR_NJIG; idt++) {
+    if (team < UWSPR_NJIG) {
+      const int idt = team;
       int ii = (idt + 1) / 2;
       if (idt % 2 == 1) ii = -ii;
       ii = 8 * ii;
-      lags[idt] = st.shift1 + ii;
-      emit(&ho[idt], st, st.worth != 0, lags[idt], st.f1, st.drift1);
+      emit(&ho[idt], st, st.worth != 0, st.shift1 + ii, st.f1, st.drift1);
     }
     // The 17 jiggered shifts as three lag groups of 6, 6, 5 with ASCENDING, evenly spaced
     // lags (shift1 - 64 + 8 m, m = 0..16), so that a group's windows overlap and K4 can keep
     // them in one LDS ring.  Shift m is try idt = 2|m-8| - (m < 8): -64 -> 15, 0 -> 0, +64 -> 16.
     for (int g = 0; g < 3; g++) {
+      if (team != UWSPR_NJIG + g) continue;
       const int n = g < 2 ? 6 : 5;
       int gl[6], idt0 = 99;
       int id[6];
@@ -392,7 +394,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
                  slot * UWSPR_NJIG + idt0, gl, n, hmap);
     }
   }
-  state[slot] = st;
+  if (team == 0) state[slot] = st;
 }
 
 // Fold of a candidate's NIN hypotheses (one wavefront each) fused with the
@@ -414,7 +416,12 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
                                        : fold_wave<false>(hin, p, h, 50.0f, nullptr, L[wv], nullptr);
   if ((threadIdx.x & 63) == 0) { sy[wv] = s; sync[h] = s; }
   __syncthreads();
-  if (threadIdx.x == 0) sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0);
+  if (STAGE == 5) {
+    if (threadIdx.x < UWSPR_NJIG + 3)
+      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x);
+  } else if (threadIdx.x == 0) {
+    sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0);
+  }
 }
 
 // out[slot]: state + per-try sync / rms / shift / symbols (cc:465-475)

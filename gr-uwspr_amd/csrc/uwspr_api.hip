@@ -50,7 +50,7 @@ static int ensure(uwspr_ctx *c, T **buf, size_t *cap, size_t need_elems) {
   return UWSPR_OK;
 }
 
-prof_scope::prof_scope(uwspr_ctx *cx, int kind, int64_t units) : c(cx), idx(-1) {
+prof_scope::prof_scope(uwspr_ctx *cx, int kind, int64_t units, bool ext_) : c(cx), idx(-1), ext(ext_) {
   if (!(c->prof_mask & (1 << kind))) return;
   ev_pair p;
   auto get = [&]() {
@@ -60,12 +60,12 @@ prof_scope::prof_scope(uwspr_ctx *cx, int kind, int64_t units) : c(cx), idx(-1) 
     return e;
   };
   p.a = get(); p.b = get(); p.kind = kind; p.units = units;
-  (void)hipEventRecord(p.a, c->stream);
+  if (!ext) (void)hipEventRecord(p.a, c->stream);
   c->prof_events.push_back(p);
   idx = (int)c->prof_events.size() - 1;
 }
 prof_scope::~prof_scope() {
-  if (idx >= 0) (void)hipEventRecord(c->prof_events[idx].b, c->stream);
+  if (idx >= 0 && !ext) (void)hipEventRecord(c->prof_events[idx].b, c->stream);
 }
 
 // slmFrequencyDrift, lib/slm.cc:36-73 (host side, used to build the offset table)

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <vector>
 
@@ -184,9 +185,23 @@ void launch_sched_finish(uwspr_ctx *c, int ncand);
 
 // profiling brackets
 struct prof_scope {
-  uwspr_ctx *c; int idx;
-  prof_scope(uwspr_ctx *c, int kind, int64_t units);
+  uwspr_ctx *c; int idx; bool ext;
+  // ext = false: events recorded on the stream before / after the bracketed launches (one
+  // marker packet each).  ext = true: the ONE launch inside the scope goes through
+  // launch_timed(), which hands the pair to hipExtLaunchKernelGGL -- the kernel's own dispatch
+  // packet carries the time stamps and no extra packet (and no ~5 us bubble) enters the queue.
+  prof_scope(uwspr_ctx *c, int kind, int64_t units, bool ext = false);
   ~prof_scope();
 };
+
+template <typename K, typename... A>
+inline void launch_timed(uwspr_ctx *c, prof_scope &ps, K kernel, dim3 grid, dim3 block, size_t shmem,
+                         A... args) {
+  if (ps.idx >= 0 && ps.ext)
+    hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)shmem, c->stream, c->prof_events[ps.idx].a,
+                          c->prof_events[ps.idx].b, 0, args...);
+  else
+    hipLaunchKernelGGL(kernel, grid, block, shmem, c->stream, args...);
+}
 
 }  // namespace uwspr
