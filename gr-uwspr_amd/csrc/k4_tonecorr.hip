@@ -955,19 +955,37 @@ __global__ __launch_bounds__(64 * K4GR_WAVES) void k4_grid(
 #pragma unroll
   for (int l = 0; l < NL; l++) { inp[l] = 0.0f; quad[l] = 0.0f; }
 
+  // dword offsets of the NL lag columns inside this wave's windows (integers, so the reads stay
+  // ds_read with compile-time column offsets); the reads of step k+1 are issued before the
+  // arithmetic of step k and pinned there
+  const float *winf = reinterpret_cast<const float *>(win);
+  int ao[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) ao[l] = 2 * ((i - i_first) * ga.wstride + ga.off[l]);
   for (int k0 = 0; k0 < 256; k0 += 16) {
+    float2 xc[NL], xn[NL];
+#pragma unroll
+    for (int l = 0; l < NL; l++) { xc[l] = *reinterpret_cast<const float2 *>(&winf[ao[l]]); xn[l] = xc[l]; }
 #pragma unroll
     for (int k = 0; k < 16; k++) {
+      if (k < 15) {
+#pragma unroll
+        for (int l = 0; l < NL; l++) xn[l] = *reinterpret_cast<const float2 *>(&winf[ao[l] + 2 * (k + 1)]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int l = 0; l < NL; l++) {
-        const float2 x = mywin[k0 + k + ga.off[l]];
-        inp[l] = (inp[l] + x.x * c) + x.y * s;     // cc:206
-        quad[l] = (quad[l] - x.x * s) + x.y * c;   // cc:207
+        inp[l] = (inp[l] + xc[l].x * c) + xc[l].y * s;     // cc:206
+        quad[l] = (quad[l] - xc[l].x * s) + xc[l].y * c;   // cc:207
       }
       const float nc = c * cd - s * sd;            // cc:193-195
       const float ns = c * sd + s * cd;
       c = nc; s = ns;
+#pragma unroll
+      for (int l = 0; l < NL; l++) xc[l] = xn[l];
     }
+#pragma unroll
+    for (int l = 0; l < NL; l++) ao[l] += 32;      // next 16 samples
   }
 
   if (ok) {
