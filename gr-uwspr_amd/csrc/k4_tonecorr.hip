@@ -682,14 +682,20 @@ void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_gr
 namespace uwspr {
 
 constexpr int K4F_PAIRS = 54;   // symbols per workgroup: 162 = 3 x 54
-constexpr int K4F_ROWDW = 34;   // dwords per staged row: 16 samples x 8 B + 8 B pad
+#ifndef K4F_CHUNK
+#define K4F_CHUNK 32
+#endif
 
-template <int NF>
+template <int NF, int CH>   // CH = samples per staged chunk (16 or 32)
 __global__ __launch_bounds__(256) void k4_fstage(
     const float2 *__restrict__ frames, int fl, int nframes, const dev_hyp *__restrict__ hyps,
     int nslots, float *__restrict__ p_out) {
+  constexpr int K4F_ROWDW = 2 * CH + 2;   // dwords per staged row: CH samples x 8 B + 8 B pad
+  constexpr int NCH = 256 / CH;           // chunks per symbol
+  constexpr int SEGS = 256 / CH;          // symbols staged per loader round
+  constexpr int NR = (K4F_PAIRS + SEGS - 1) / SEGS;
   __shared__ __align__(16) float smp[K4F_PAIRS * K4F_ROWDW];
-  __shared__ __align__(16) float2 tab[4][16][NF];
+  __shared__ __align__(16) float2 tab[4][CH][NF];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -719,23 +725,23 @@ __global__ __launch_bounds__(256) void k4_fstage(
   const bool skip_mid = hyps[(size_t)slot * NF + NF / 2].frame <= -2;
   const float delta = ((float)tone - 1.5f) * 1.46484375f;                    // cc:148
 
-  // ---- loader: round r of a chunk = symbol 16 r + tid/16, sample tid%16 ----
-  const int kk = tid & 15, seg = tid >> 4;
+  // ---- loader: round r of a chunk = symbol SEGS r + tid/CH, sample tid%CH ----
+  const int kk = tid % CH, seg = tid / CH;
   const float2 *fb = frames + (long long)h0.frame * fl;
   const int nb0 = h0.lag + 256 * (part * K4F_PAIRS);
   const bool interior = (nb0 > 0) && (nb0 + 256 * K4F_PAIRS < fl);          // workgroup-uniform
-  float2 stage[4];
-  int nrow[4];
+  float2 stage[NR];
+  int nrow[NR];
 #pragma unroll
-  for (int r = 0; r < 4; r++) nrow[r] = nb0 + 256 * min(16 * r + seg, K4F_PAIRS - 1) + kk;
+  for (int r = 0; r < NR; r++) nrow[r] = nb0 + 256 * min(SEGS * r + seg, K4F_PAIRS - 1) + kk;
   auto load_chunk = [&](int c) {
     if (interior) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) stage[r] = fb[nrow[r] + 16 * c];
+      for (int r = 0; r < NR; r++) stage[r] = fb[nrow[r] + CH * c];
     } else {
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int n = nrow[r] + 16 * c;
+      for (int r = 0; r < NR; r++) {
+        const int n = nrow[r] + CH * c;
         const bool inr = (n > 0) && (n < fl);      // cc:205, sample 0 excluded
         const float2 v = fb[min(max(n, 0), fl - 1)];
         stage[r] = inr ? v : make_float2(0.0f, 0.0f);
@@ -744,8 +750,8 @@ __global__ __launch_bounds__(256) void k4_fstage(
   };
   auto store_chunk = [&]() {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int pj = 16 * r + seg;
+    for (int r = 0; r < NR; r++) {
+      const int pj = SEGS * r + seg;
       if (pj < K4F_PAIRS) *reinterpret_cast<float2 *>(&smp[pj * K4F_ROWDW + 2 * kk]) = stage[r];
     }
   };
@@ -772,12 +778,12 @@ __global__ __launch_bounds__(256) void k4_fstage(
     load_chunk(0);
     auto walk = [&](auto skip_tag) {
       constexpr bool SKIP = decltype(skip_tag)::value;
-      for (int ch = 0; ch < 16; ch++) {
+      for (int ch = 0; ch < NCH; ch++) {
         __syncthreads();              // the previous chunk has been read by everyone
         store_chunk();
         if (lane < NF) {
 #pragma unroll
-          for (int k = 0; k < 16; k++) {
+          for (int k = 0; k < CH; k++) {
             tab[tone][k][lane] = make_float2(cq, sq);
             const float nc = cq * cdq - sq * sdq;   // cc:193-195
             const float ns = cq * sdq + sq * cdq;
@@ -785,9 +791,9 @@ __global__ __launch_bounds__(256) void k4_fstage(
           }
         }
         __syncthreads();
-        load_chunk(min(ch + 1, 15));  // in flight during the arithmetic (no branch around it)
+        load_chunk(min(ch + 1, NCH - 1));  // in flight during the arithmetic (no branch around it)
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
+        for (int k = 0; k < CH; k++) {
           const float2 x = *reinterpret_cast<const float2 *>(&smp[row * K4F_ROWDW + 2 * k]);
 #pragma unroll
           for (int q = 0; q < NF; q++) {
@@ -811,13 +817,13 @@ __global__ __launch_bounds__(256) void k4_fstage(
       cd[q] = (float)cs; sd[q] = (float)sn; c[q] = 1.0f; s[q] = 0.0f;
     }
     load_chunk(0);
-    for (int ch = 0; ch < 16; ch++) {
+    for (int ch = 0; ch < NCH; ch++) {
       __syncthreads();
       store_chunk();
       __syncthreads();
-      load_chunk(min(ch + 1, 15));
+      load_chunk(min(ch + 1, NCH - 1));
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
+      for (int k = 0; k < CH; k++) {
         const float2 x = *reinterpret_cast<const float2 *>(&smp[row * K4F_ROWDW + 2 * k]);
 #pragma unroll
         for (int q = 0; q < NF; q++) {
@@ -845,7 +851,7 @@ void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_
                             int64_t nhyps, float4 *p) {
   if (nslots <= 0) return;
   prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
-  launch_timed(c, ps, k4_fstage<5>, dim3(3u * (unsigned)nslots), dim3(256), 0,
+  launch_timed(c, ps, (k4_fstage<5, K4F_CHUNK>), dim3(3u * (unsigned)nslots), dim3(256), 0,
                (const float2 *)frames, c->fc.fl, B, hyps, nslots, (float *)p);
 }
 
