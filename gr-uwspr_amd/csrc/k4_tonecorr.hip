@@ -467,7 +467,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   constexpr int Q = (15 + W) / 16;         // furthest slot a chunk reaches ahead
   constexpr int M = Q + 1;                 // ring slots
   constexpr int NSLOT = 16 + Q;            // slots a pair needs in all
-  constexpr int RS = 32 * M + 2;           // dwords per pair row (rows start on distinct bank pairs)
+  constexpr int RS = 32 * M + 4;           // dwords per pair row: 16-byte aligned, rows of a lane group on distinct banks
   __shared__ __align__(16) float lds_all[K4G_WAVES][PPW * RS];
 
   const int lane = threadIdx.x & 63;
@@ -579,40 +579,57 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
     for (int ch = 0; ch < 16; ch++) {
       // in flight during the chunk's arithmetic (the last chunk re-fetches the last slot: no
       // branch here or after the arithmetic, or the compiler sinks the arithmetic past it)
+#if !(defined(K4R_EXP) && (K4R_EXP & 1))   // timing experiment 1: no global loads in the walk
       load_slot(min(ch + Q + 1, NSLOT - 1));
+#endif
+#if !(defined(K4R_EXP) && (K4R_EXP & 2))   // timing experiment 2: no fences / LDS stores in the walk
       wave_lds_fence();                      // the slots written so far are visible
-      float2 xc[NL], xn[NL];
+#endif
+      // Two samples per read: STEP is even, so sample k + STEP l of an even step k and its
+      // successor sit in one 16-byte-aligned LDS word pair -- one ds_read_b128 per lag and two
+      // steps (an LDS read costs the SIMD about as much issue time as five arithmetic
+      // instructions, tools/ring_probe.hip).  The reads of steps k+2, k+3 are issued before
+      // the arithmetic of steps k, k+1 and pinned there.
+      static_assert(STEP % 2 == 0, "sample pairs must not straddle lags");
+      float4 vc[NL], vn[NL];
 #pragma unroll
       for (int l = 0; l < NL; l++) {
-        if (SKIP && l == 2) { xc[l] = make_float2(0.0f, 0.0f); xn[l] = xc[l]; continue; }
-        xc[l] = *reinterpret_cast<const float2 *>(&lds[sa[(STEP * l) >> 4] + 2 * ((STEP * l) & 15)]);
+        if (SKIP && l == 2) { vc[l] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); vn[l] = vc[l]; continue; }
+        vc[l] = *reinterpret_cast<const float4 *>(&lds[sa[(STEP * l) >> 4] + 2 * ((STEP * l) & 15)]);
+        vn[l] = vc[l];
       }
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        if (k < 15) {
+      for (int k = 0; k < 16; k += 2) {
+        if (k < 14) {
 #pragma unroll
           for (int l = 0; l < NL; l++) {
             if (SKIP && l == 2) continue;
-            const int o = k + 1 + STEP * l;
-            xn[l] = *reinterpret_cast<const float2 *>(&lds[sa[o >> 4] + 2 * (o & 15)]);
+            const int o = k + 2 + STEP * l;
+            vn[l] = *reinterpret_cast<const float4 *>(&lds[sa[o >> 4] + 2 * (o & 15)]);
           }
         }
-        __builtin_amdgcn_sched_barrier(0);   // keep the reads of step k+1 ahead of step k's arithmetic
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int l = 0; l < NL; l++) {
-          if (SKIP && l == 2) continue;
-          inp[l] = (inp[l] + xc[l].x * c) + xc[l].y * s;     // cc:206
-          quad[l] = (quad[l] - xc[l].x * s) + xc[l].y * c;   // cc:207
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            if (SKIP && l == 2) continue;
+            const float xx = half ? vc[l].z : vc[l].x, xy = half ? vc[l].w : vc[l].y;
+            inp[l] = (inp[l] + xx * c) + xy * s;     // cc:206
+            quad[l] = (quad[l] - xx * s) + xy * c;   // cc:207
+          }
+          const float nc = c * cd - s * sd;          // cc:193-195
+          const float ns = c * sd + s * cd;
+          c = nc; s = ns;
         }
-        const float nc = c * cd - s * sd;                    // cc:193-195
-        const float ns = c * sd + s * cd;
-        c = nc; s = ns;
 #pragma unroll
-        for (int l = 0; l < NL; l++) xc[l] = xn[l];
+        for (int l = 0; l < NL; l++) vc[l] = vn[l];
       }
       // slot ch is finished with: its position takes slot ch + Q + 1, and the addresses rotate
+#if !(defined(K4R_EXP) && (K4R_EXP & 2))
       wave_lds_fence();
       store_slot(wpos);
+#endif
       wpos = (wpos + 1 == M) ? 0 : wpos + 1;
       const int first = sa[0];
 #pragma unroll
