@@ -22,7 +22,7 @@
 // Samples reach the lanes through LDS: a wavefront's symbol windows are runs of
 // 2 KB in HBM; per 16-sample chunk the wave loads them cooperatively (16 lanes x
 // 8 B = one 128-B run per window) into a per-wave LDS image whose rows are
-// padded to 136 B, so the per-lane column reads (ds_read_b64) are bank-conflict
+// padded to 144 B, so the per-lane column reads (ds_read_b128, two samples each) are bank-conflict
 // free (lanes of one pair read the same address: broadcast).  The next chunk's
 // global loads are in flight while the current chunk is computed.
 //
@@ -42,7 +42,7 @@
 namespace uwspr {
 
 constexpr int K4_WAVES = 4;
-constexpr int K4_ROWDW = 34;  // dwords per staged row: 16 samples x 8 B + 8 B pad
+constexpr int K4_ROWDW = 36;  // dwords per staged row: 16 samples x 8 B + 16 B pad (16-byte aligned rows)
 
 // 2*pi*dt with dt = (float)(1/375) -- cc:146,188: `2*M_PI*dt*(fp+delta[j])`
 constexpr double kTwoPiDt = 2.0 * 3.14159265358979323846 * (double)(float)(1.0 / 375.0);
@@ -169,20 +169,25 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
       *reinterpret_cast<float2 *>(&lds[(4 * t + segq) * K4_ROWDW + 2 * kk]) = stage[t];
     wave_lds_fence();
     if (ch < 15) load_chunk(ch + 1);
-    float2 xnext = *reinterpret_cast<const float2 *>(&lds[pr * K4_ROWDW]);
+    // two samples per LDS read (ds_read_b128); the next pair is in flight during these two steps
+    float4 vnext = *reinterpret_cast<const float4 *>(&lds[pr * K4_ROWDW]);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      const float2 x = xnext;  // the read of sample k+1 is in flight during step k
-      if (k < 15) xnext = *reinterpret_cast<const float2 *>(&lds[pr * K4_ROWDW + 2 * (k + 1)]);
+    for (int k = 0; k < 16; k += 2) {
+      const float4 v = vnext;
+      if (k < 14) vnext = *reinterpret_cast<const float4 *>(&lds[pr * K4_ROWDW + 2 * (k + 2)]);
 #pragma unroll
-      for (int j = 0; j < T; j++) {
-        // cc:206-207, left to right
-        inp[j] = (inp[j] + x.x * c[j]) + x.y * s[j];
-        quad[j] = (quad[j] - x.x * s[j]) + x.y * c[j];
-        // cc:193-195
-        const float nc = c[j] * cd[j] - s[j] * sd[j];
-        const float ns = c[j] * sd[j] + s[j] * cd[j];
-        c[j] = nc; s[j] = ns;
+      for (int half = 0; half < 2; half++) {
+        const float xx = half ? v.z : v.x, xy = half ? v.w : v.y;
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+          // cc:206-207, left to right
+          inp[j] = (inp[j] + xx * c[j]) + xy * s[j];
+          quad[j] = (quad[j] - xx * s[j]) + xy * c[j];
+          // cc:193-195
+          const float nc = c[j] * cd[j] - s[j] * sd[j];
+          const float ns = c[j] * sd[j] + s[j] * cd[j];
+          c[j] = nc; s[j] = ns;
+        }
       }
     }
   }
@@ -707,12 +712,12 @@ template <int NF, int CH>   // CH = samples per staged chunk (16 or 32)
 __global__ __launch_bounds__(256) void k4_fstage(
     const float2 *__restrict__ frames, int fl, int nframes, const dev_hyp *__restrict__ hyps,
     int nslots, float *__restrict__ p_out) {
-  constexpr int K4F_ROWDW = 2 * CH + 2;   // dwords per staged row: CH samples x 8 B + 8 B pad
+  constexpr int K4F_ROWDW = 2 * CH + 4;   // dwords per staged row: CH samples x 8 B + 16 B pad (16-byte aligned)
   constexpr int NCH = 256 / CH;           // chunks per symbol
   constexpr int SEGS = 256 / CH;          // symbols staged per loader round
   constexpr int NR = (K4F_PAIRS + SEGS - 1) / SEGS;
   __shared__ __align__(16) float smp[K4F_PAIRS * K4F_ROWDW];
-  __shared__ __align__(16) float2 tab[4][CH][NF];
+  __shared__ __align__(16) float4 tab[4][CH / 2][NF];   // (c, s) of steps 2j and 2j+1 per frequency
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -801,7 +806,7 @@ __global__ __launch_bounds__(256) void k4_fstage(
         if (lane < NF) {
 #pragma unroll
           for (int k = 0; k < CH; k++) {
-            tab[tone][k][lane] = make_float2(cq, sq);
+            reinterpret_cast<float2 *>(&tab[tone][k >> 1][lane])[k & 1] = make_float2(cq, sq);
             const float nc = cq * cdq - sq * sdq;   // cc:193-195
             const float ns = cq * sdq + sq * cdq;
             cq = nc; sq = ns;
@@ -810,14 +815,17 @@ __global__ __launch_bounds__(256) void k4_fstage(
         __syncthreads();
         load_chunk(min(ch + 1, NCH - 1));  // in flight during the arithmetic (no branch around it)
 #pragma unroll
-        for (int k = 0; k < CH; k++) {
-          const float2 x = *reinterpret_cast<const float2 *>(&smp[row * K4F_ROWDW + 2 * k]);
+        for (int k = 0; k < CH; k += 2) {
+          // two samples and two phasor steps per LDS read (ds_read_b128)
+          const float4 x = *reinterpret_cast<const float4 *>(&smp[row * K4F_ROWDW + 2 * k]);
 #pragma unroll
           for (int q = 0; q < NF; q++) {
             if (SKIP && q == NF / 2) continue;
-            const float2 ph = tab[tone][k][q];     // same address in every lane: LDS broadcast
-            inp[q] = (inp[q] + x.x * ph.x) + x.y * ph.y;      // cc:206
+            const float4 ph = tab[tone][k >> 1][q];   // same address in every lane: LDS broadcast
+            inp[q] = (inp[q] + x.x * ph.x) + x.y * ph.y;      // cc:206, step k
             quad[q] = (quad[q] - x.x * ph.y) + x.y * ph.x;    // cc:207
+            inp[q] = (inp[q] + x.z * ph.z) + x.w * ph.w;      // step k + 1
+            quad[q] = (quad[q] - x.z * ph.w) + x.w * ph.z;
           }
         }
       }
@@ -840,15 +848,19 @@ __global__ __launch_bounds__(256) void k4_fstage(
       __syncthreads();
       load_chunk(min(ch + 1, NCH - 1));
 #pragma unroll
-      for (int k = 0; k < CH; k++) {
-        const float2 x = *reinterpret_cast<const float2 *>(&smp[row * K4F_ROWDW + 2 * k]);
+      for (int k = 0; k < CH; k += 2) {
+        const float4 x4 = *reinterpret_cast<const float4 *>(&smp[row * K4F_ROWDW + 2 * k]);
 #pragma unroll
-        for (int q = 0; q < NF; q++) {
-          inp[q] = (inp[q] + x.x * c[q]) + x.y * s[q];      // cc:206
-          quad[q] = (quad[q] - x.x * s[q]) + x.y * c[q];    // cc:207
-          const float nc = c[q] * cd[q] - s[q] * sd[q];     // cc:193-195
-          const float ns = c[q] * sd[q] + s[q] * cd[q];
-          c[q] = nc; s[q] = ns;
+        for (int half = 0; half < 2; half++) {
+          const float xx = half ? x4.z : x4.x, xy = half ? x4.w : x4.y;
+#pragma unroll
+          for (int q = 0; q < NF; q++) {
+            inp[q] = (inp[q] + xx * c[q]) + xy * s[q];        // cc:206
+            quad[q] = (quad[q] - xx * s[q]) + xy * c[q];      // cc:207
+            const float nc = c[q] * cd[q] - s[q] * sd[q];     // cc:193-195
+            const float ns = c[q] * sd[q] + s[q] * cd[q];
+            c[q] = nc; s[q] = ns;
+          }
         }
       }
     }
