@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
     int G, float *__restrict__ p_out) {
   constexpr int PPW = 16;                  // (group, symbol) pairs per wavefront, 4 tone lanes each
   constexpr int NLP = (NL + 1) & ~1;       // lags per sample slot, padded to even (16-B aligned slots)
-  constexpr int ROWDW = 32 * NLP + 4;      // dwords per pair row: [8 sample pairs][NLP lags][2] float2 + 16 B pad
+  constexpr int ROWDW = 32 * NLP + 4;      // dwords per pair row: [16 samples][NLP lags] float2 + 16 B pad
   constexpr int NLD = 4 * NL;              // cooperative loads per lane per chunk
   __shared__ __align__(16) float lds_all[K4G_WAVES][PPW * ROWDW];
 
@@ -381,39 +381,39 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
 #pragma unroll
     for (int t = 0; t < NLD; t++) {
       const int l = t >> 2, j = t & 3;
-      // row layout [8 sample pairs][NLP lags][2 samples]: one 16-byte word = samples 2m, 2m+1 of a lag
-      *reinterpret_cast<float2 *>(&lds[(4 * j + segq) * ROWDW + (((kk >> 1) * NLP + l) * 2 + (kk & 1)) * 2]) = stage[t];
+      *reinterpret_cast<float2 *>(&lds[(4 * j + segq) * ROWDW + (kk * NLP + l) * 2]) = stage[t];
     }
     wave_lds_fence();
     if (ch < 15) load_chunk(ch + 1);
-    // one ds_read_b128 per lag and two samples; the reads of the next sample pair are issued
-    // before the arithmetic of this one so their LDS latency is covered
-    auto read_pair = [&](int m, float4 (&v)[NL]) {
-      const float *slot = &lds[pr * ROWDW + m * NLP * 4];
+    // the NL lags of a sample slot are contiguous (16-byte reads); the reads of step k+1
+    // are issued before the arithmetic of step k so their LDS latency is covered
+    auto read_slot = [&](int k, float2 (&x)[NLP]) {
+      const float *slot = &lds[pr * ROWDW + k * NLP * 2];
 #pragma unroll
-      for (int l = 0; l < NL; l++) v[l] = *reinterpret_cast<const float4 *>(slot + 4 * l);
-    };
-    float4 vc[NL], vn[NL];
-    read_pair(0, vc);
-#pragma unroll
-    for (int l = 0; l < NL; l++) vn[l] = vc[l];
-#pragma unroll
-    for (int k = 0; k < 16; k += 2) {
-      if (k < 14) read_pair((k >> 1) + 1, vn);
-#pragma unroll
-      for (int half = 0; half < 2; half++) {
-#pragma unroll
-        for (int l = 0; l < NL; l++) {
-          const float xx = half ? vc[l].z : vc[l].x, xy = half ? vc[l].w : vc[l].y;
-          inp[l] = (inp[l] + xx * c) + xy * s;     // cc:206
-          quad[l] = (quad[l] - xx * s) + xy * c;   // cc:207
+      for (int q = 0; q < NLP / 2; q++) {
+        if (2 * q + 1 < NL || (NL & 1) == 0) {
+          const float4 v = *reinterpret_cast<const float4 *>(slot + 4 * q);
+          x[2 * q] = make_float2(v.x, v.y); x[2 * q + 1] = make_float2(v.z, v.w);
+        } else {
+          x[2 * q] = *reinterpret_cast<const float2 *>(slot + 4 * q);
         }
-        const float nc = c * cd - s * sd;          // cc:193-195
-        const float ns = c * sd + s * cd;
-        c = nc; s = ns;
       }
+    };
+    float2 xc[NLP], xn[NLP];
+    read_slot(0, xc);
 #pragma unroll
-      for (int l = 0; l < NL; l++) vc[l] = vn[l];
+    for (int k = 0; k < 16; k++) {
+      if (k < 15) read_slot(k + 1, xn);
+#pragma unroll
+      for (int l = 0; l < NL; l++) {
+        inp[l] = (inp[l] + xc[l].x * c) + xc[l].y * s;     // cc:206
+        quad[l] = (quad[l] - xc[l].x * s) + xc[l].y * c;   // cc:207
+      }
+      const float nc = c * cd - s * sd;                    // cc:193-195
+      const float ns = c * sd + s * cd;
+      c = nc; s = ns;
+#pragma unroll
+      for (int l = 0; l < NLP; l++) xc[l] = xn[l];
     }
   }
 

@@ -1,68 +1,75 @@
-// ring_probe.hip -- issue rate of the lag-group walk (1 phasor recurrence + NL multiply-accumulate
-// pairs per sample, NL LDS reads per sample) as a function of NL, waves per SIMD and of where the
-// samples come from.  Diagnostic only.
+// ring_probe.hip -- issue rate of the lag-group walk: T tone phasors per lane, NL lags, one
+// ds_read_b128 per lag and two samples; VALU per sample = 6T + 8 T NL.  How does the rate depend
+// on LDS bytes per arithmetic instruction and on waves per SIMD?  Diagnostic only.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #pragma clang fp contract(off)
 
-template <int NL, int MODE>   // MODE 0: NL ds_read_b64 per step; 1: registers (laundered, no LDS); 2: one b64 read per step
+template <int NL, int T, bool LDS>
 __global__ __launch_bounds__(128) void probe(float *out, int iters, float a, float b) {
-  __shared__ float lds[2][16 * 200];
+  __shared__ __align__(16) float lds[2][32 * 132];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int pr = lane >> 2;
-  for (int k = lane; k < 16 * 200; k += 64) lds[wv][k] = a * k + lane;
+  const int pr = lane / (4 / T);
+  for (int k = lane; k < 32 * 132; k += 64) lds[wv][k] = a * k + lane;
   __syncthreads();
-  float c = 1.0f, s = 0.0f, cd = a, sd = b;
-  float inp[NL], quad[NL];
-  for (int l = 0; l < NL; l++) { inp[l] = 0; quad[l] = 0; }
-  const float *row = &lds[wv][pr * 200];
-  float2 xr[NL];
-  for (int l = 0; l < NL; l++) xr[l] = make_float2(a + l, b - l);
+  float c[T], s[T], cd[T], sd[T];
+  float inp[T][NL], quad[T][NL];
+  for (int j = 0; j < T; j++) { c[j] = 1.0f; s[j] = 0.0f; cd[j] = a + 1e-3f * j; sd[j] = b;
+    for (int l = 0; l < NL; l++) { inp[j][l] = 0; quad[j][l] = 0; } }
+  const float *row = &lds[wv][pr * 132];
+  float4 v[NL];
+  for (int l = 0; l < NL; l++) v[l] = make_float4(a + l, b - l, a - l, b + l);
   for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-      float2 x[NL];
+    for (int k = 0; k < 16; k += 2) {
+      if (LDS) {
 #pragma unroll
-      for (int l = 0; l < NL; l++) {
-        if (MODE == 0) x[l] = *reinterpret_cast<const float2 *>(&row[2 * (k + 8 * l)]);
-        else if (MODE == 2) x[l] = (l == 0) ? *reinterpret_cast<const float2 *>(&row[2 * k]) : xr[l];
-        else x[l] = xr[l];
-        if (MODE != 0) { asm volatile("" : "+v"(x[l].x), "+v"(x[l].y)); }
+        for (int l = 0; l < NL; l++) v[l] = *reinterpret_cast<const float4 *>(&row[2 * (k + 8 * l)]);
       }
 #pragma unroll
-      for (int l = 0; l < NL; l++) {
-        inp[l] = (inp[l] + x[l].x * c) + x[l].y * s;
-        quad[l] = (quad[l] - x[l].x * s) + x[l].y * c;
+      for (int half = 0; half < 2; half++) {
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+#pragma unroll
+          for (int l = 0; l < NL; l++) {
+            const float xx = half ? v[l].z : v[l].x, xy = half ? v[l].w : v[l].y;
+            inp[j][l] = (inp[j][l] + xx * c[j]) + xy * s[j];
+            quad[j][l] = (quad[j][l] - xx * s[j]) + xy * c[j];
+          }
+          const float nc = c[j] * cd[j] - s[j] * sd[j], ns = c[j] * sd[j] + s[j] * cd[j];
+          c[j] = nc; s[j] = ns;
+        }
       }
-      const float nc = c * cd - s * sd, ns = c * sd + s * cd;
-      c = nc; s = ns;
     }
   }
   float r = 0;
-  for (int l = 0; l < NL; l++) r += inp[l] + quad[l];
+  for (int j = 0; j < T; j++) for (int l = 0; l < NL; l++) r += inp[j][l] + quad[j][l];
   out[blockIdx.x * 128 + threadIdx.x] = r;
 }
 
-template <int NL, int MODE>
+template <int NL, int T, bool LDS>
 void run(int waves_per_simd, int iters) {
-  int blocks = 256 * 2 * waves_per_simd;   // 2 waves per block, 4 SIMDs per CU
+  int blocks = 256 * 2 * waves_per_simd;
   float *out; hipMalloc(&out, blocks * 128 * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  probe<NL, MODE><<<blocks, 128>>>(out, 4, 0.999f, 0.01f);
+  probe<NL, T, LDS><<<blocks, 128>>>(out, 4, 0.999f, 0.01f);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  probe<NL, MODE><<<blocks, 128>>>(out, iters, 0.999f, 0.01f);
+  probe<NL, T, LDS><<<blocks, 128>>>(out, iters, 0.999f, 0.01f);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  double instr = (double)blocks * 2 * iters * 16 * (6 + 8 * NL);
-  printf("NL=%d mode=%d waves/SIMD=%d  %.3f ms  VALU wave-instr/cycle/SIMD@2.4GHz=%.3f\n", NL, MODE, waves_per_simd, ms,
-         instr / (ms * 1e-3) / 1024 / 2.4e9);
+  double instr = (double)blocks * 2 * iters * 16 * (6 * T + 8 * T * NL);
+  printf("NL=%d T=%d lds=%d waves/SIMD=%d  %.3f ms  VALU wave-instr/cycle/SIMD@2.4GHz=%.3f\n", NL, T, (int)LDS,
+         waves_per_simd, ms, instr / (ms * 1e-3) / 1024 / 2.4e9);
   hipFree(out);
 }
 
 int main() {
-  for (int w : {2, 4, 8}) {
-    run<1, 0>(w, 2048); run<2, 0>(w, 2048); run<6, 0>(w, 512); run<6, 1>(w, 512); run<6, 2>(w, 512);
+  for (int w : {2, 3, 4}) {
+    run<6, 1, false>(w, 512); run<6, 1, true>(w, 512);
+    run<6, 2, false>(w, 256); run<6, 2, true>(w, 256);
+    run<3, 4, false>(w, 256); run<3, 4, true>(w, 256);
+    run<6, 4, true>(w, 128);
   }
   return 0;
 }
