@@ -521,3 +521,36 @@ def test_schedule_on_a_silent_frame(ctx, G, oracle):
             if d["worth_a_try"]:
                 assert (o["symbols"] == d["symbols"]).all()
     assert int(out[0, 0]["worth_a_try"]) == 0 and int(out[1, 0]["worth_a_try"]) == 1
+
+
+def test_other_carrier_and_frame_parameters(G, oracle):
+    """Parameters away from the flowgraph defaults: cf = 2000 (the SLM Doppler reach, hence
+    the coarse tile width, scales with cf), a wide band with few candidates kept
+    (maxfreqs = 3), cf = 500.  Candidates and the whole schedule against the oracle.
+    cf = 3000 needs a coarse tile beyond the 160 KB of LDS: a status code, not a crash."""
+    with pytest.raises(G.UwsprError) as ei:
+        G.Context(cf=3000, halfbandwidth=20)
+    assert ei.value.status == -3 and "LDS" in str(ei.value)   # UWSPR_ERR_UNSUPPORTED
+    frames = G.synth.make_frames(3, seed=271828, snr_db=-16.0, halfbandwidth=20)
+    for kw in ({"cf": 2000, "halfbandwidth": 20}, {"halfbandwidth": 30, "maxfreqs": 3, "maxdrift": 1},
+               {"cf": 500, "halfbandwidth": 12}):
+        c = G.Context(**kw)
+        try:
+            cands, out = c.pipeline_batch(frames, max_per_frame=2)
+        finally:
+            c.close()
+        f = oracle.FDR(**kw)
+        cf = kw.get("cf", 1500)
+        for b in range(3):
+            exp = f.transform(frames[b])
+            assert len(cands[b]) == len(exp), (kw, b)
+            for j, (a, e) in enumerate(zip(cands[b], exp)):
+                cand_equal(a, e)
+                if j < 2:
+                    d = oracle.demod_candidate(e, cf, frames[b])
+                    o = out[b, j]
+                    assert int(o["worth_a_try"]) == d["worth_a_try"] and int(o["shift1"]) == d["shift1"], (kw, b, j)
+                    for k in ("f1", "drift1", "sync1"):
+                        assert np.float32(o[k]).tobytes() == np.float32(d[k]).tobytes(), (kw, b, j, k)
+                    if d["worth_a_try"]:
+                        assert (o["symbols"] == d["symbols"]).all(), (kw, b, j)
