@@ -42,7 +42,7 @@ __host__ __device__ inline k3_lds_layout k3_layout(const fdr_consts &f) {
   k3_lds_layout l;
   l.tile = 0;
   l.uoff = l.tile + (size_t)f.n * f.nc * 16;
-  l.sync = l.uoff + (size_t)UWSPR_NIFR * f.umax * 41 * 4;
+  l.sync = l.uoff + (f.uoff_global ? 0 : (size_t)UWSPR_NIFR * f.umax * 41 * 4);
   l.umap = l.sync + (size_t)UWSPR_NIFR * UWSPR_NK0 * f.umax * 4;
   l.total = l.umap + (((size_t)UWSPR_NIFR * f.cell_hyps * 2 + 15) & ~(size_t)15);
   // after the evaluation the tile + offset-table range is reused for the expanded
@@ -92,7 +92,10 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
                             ieee_sqrtf(pr[3]));
   }
   const int nuw = UWSPR_NIFR * f.umax * 41;
-  for (int idx = tid; idx < nuw; idx += K3_THREADS) uoff[idx] = uoff_tab[(size_t)r0 * f.umax * 41 + idx];
+  // (large cf / maxdrift: the sequences stay in HBM/L2 and only the tile and the metrics use LDS)
+  if (!f.uoff_global)
+    for (int idx = tid; idx < nuw; idx += K3_THREADS) uoff[idx] = uoff_tab[(size_t)r0 * f.umax * 41 + idx];
+  const uint32_t *uo_base = f.uoff_global ? uoff_tab + (size_t)r0 * f.umax * 41 : uoff;
   for (int idx = tid; idx < UWSPR_NIFR * f.cell_hyps; idx += K3_THREADS)
     umap[idx] = umap_tab[(size_t)r0 * f.cell_hyps + idx];
   __syncthreads();
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   for (int g = tid; g < neval; g += K3_THREADS) {
     const int cell = g / f.umax, u = g - cell * f.umax;
     const int ifr_i = cell / UWSPR_NK0, k0 = cell - ifr_i * UWSPR_NK0;
-    const uint32_t *ot = uoff + (ifr_i * f.umax + u) * 41;
+    const uint32_t *ot = uo_base + (ifr_i * f.umax + u) * 41;
     int idx = k0 * f.nc + ifr_i - f.off_min;  // tile index of (row k0, offset 0)
     float ss = 0.0f, pw = 0.0f;
     // Software pipeline: the 4 gathers of symbol group k4+1 (and the offset word

@@ -239,6 +239,8 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
         offw[((size_t)r * f.umax + u) * 41 + k4] = v;
       }
     }
+  f.uoff_global = 0;
+  if (coarse_lds_bytes(f) > 160 * 1024) f.uoff_global = 1;   // keep the offset sequences out of LDS
   if (coarse_lds_bytes(f) > 160 * 1024)
     return fail(c, UWSPR_ERR_UNSUPPORTED, "coarse search needs %zu B of LDS (> 160 KiB): reduce maxdrift/cf",
                 coarse_lds_bytes(f));

@@ -87,6 +87,7 @@ struct fdr_consts {
   int ifr_lo, n_ifr;              // rows of the offset table
   int umax;                       // distinct offset sequences per cell (max over rows)
   int cand_slots;                 // max candidates a frame can yield
+  int uoff_global;                // K3 reads the offset sequences from HBM/L2 (LDS too small to hold them)
   float df, min_snr, min_snr_floor, threshold;
 };
 

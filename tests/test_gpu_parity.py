@@ -524,16 +524,17 @@ def test_schedule_on_a_silent_frame(ctx, G, oracle):
 
 
 def test_other_carrier_and_frame_parameters(G, oracle):
-    """Parameters away from the flowgraph defaults: cf = 2000 (the SLM Doppler reach, hence
-    the coarse tile width, scales with cf), a wide band with few candidates kept
+    """Parameters away from the flowgraph defaults: cf = 2000 and 3000 (the SLM Doppler reach,
+    hence the coarse tile width, scales with cf; at 3000 the offset sequences no longer fit
+    LDS beside the tile and are read from HBM/L2), a wide band with few candidates kept
     (maxfreqs = 3), cf = 500.  Candidates and the whole schedule against the oracle.
-    cf = 3000 needs a coarse tile beyond the 160 KB of LDS: a status code, not a crash."""
+    A tile beyond the 160 KB of LDS altogether is a status code, not a crash."""
     with pytest.raises(G.UwsprError) as ei:
-        G.Context(cf=3000, halfbandwidth=20)
+        G.Context(cf=6000, halfbandwidth=20)
     assert ei.value.status == -3 and "LDS" in str(ei.value)   # UWSPR_ERR_UNSUPPORTED
     frames = G.synth.make_frames(3, seed=271828, snr_db=-16.0, halfbandwidth=20)
-    for kw in ({"cf": 2000, "halfbandwidth": 20}, {"halfbandwidth": 30, "maxfreqs": 3, "maxdrift": 1},
-               {"cf": 500, "halfbandwidth": 12}):
+    for kw in ({"cf": 2000, "halfbandwidth": 20}, {"cf": 3000, "halfbandwidth": 20},
+               {"halfbandwidth": 30, "maxfreqs": 3, "maxdrift": 1}, {"cf": 500, "halfbandwidth": 12}):
         c = G.Context(**kw)
         try:
             cands, out = c.pipeline_batch(frames, max_per_frame=2)
