@@ -19,52 +19,90 @@ __device__ __constant__ uint32_t kPr3[6] = UWSPR_PR3_WORDS;
 __device__ __forceinline__ bool pr3_rt(int i) { return (kPr3[i >> 5] >> (i & 31)) & 1u; }
 
 // ------------------------------------------------------------------- K5 fold
-// One lane per hypothesis, 162 sequential steps in symbol order: the
-// reference's accumulation order for totp / ss / fsum / f2sum.  Kept as the A/B
-// alternative (UWSPR_K5_LANES=1) of the wave-per-hypothesis form below, which is
-// faster at every size measured (its row reads are coalesced; here each lane
-// walks its own 2.6 KB row).
-__global__ __launch_bounds__(256) void k5_fold(const dev_hyp *__restrict__ hyps,
-                                               const float4 *__restrict__ p, int H,
-                                               float symfac, float *__restrict__ sync,
-                                               uint8_t *__restrict__ symbols) {
-  const int h = blockIdx.x * 256 + threadIdx.x;
-  if (h >= H) return;
-  const float4 *ph = p + (size_t)h * UWSPR_NSYM;
-  if (hyps[h].frame < 0) {
-    sync[h] = -1e30f;
-    if (symbols)
-      for (int i = 0; i < UWSPR_NSYM; i++) symbols[(size_t)h * UWSPR_NSYM + i] = 0;
-    return;
-  }
-  float ss = 0.0f, totp = 0.0f, fsum = 0.0f, f2sum = 0.0f;
+__device__ __forceinline__ void k5_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// Lanes form, for launches with tens of thousands of hypotheses (the configs[2]
+// sweep): one lane per hypothesis walks its 162 symbols in order -- the reference's
+// accumulation order for totp / ss / fsum / f2sum -- with every lane busy, where the
+// wave form below spends a whole wavefront on four serial sums.  The rows are 2.6 KB
+// apart, so a wavefront brings 9 symbols of its 64 hypotheses into LDS at a time
+// with 144-byte runs (576 float4, 9 per lane) and each lane then reads its own 9
+// (row stride 36 dwords: conflict-free ds_read_b128); the soft-symbol bytes go
+// back the same way (LDS image, then 10 368 contiguous bytes per wavefront).
+constexpr int K5L_CH = 9;                       // symbols per staged chunk: 162 = 18 x 9
+__global__ __launch_bounds__(64) void k5_fold(const dev_hyp *__restrict__ hyps,
+                                              const float4 *__restrict__ p, int H,
+                                              float symfac, float *__restrict__ sync,
+                                              uint8_t *__restrict__ symbols) {
+  __shared__ __align__(16) float4 tile[64 * K5L_CH];          // [hyp][9]
+  __shared__ __align__(16) uint8_t bytes[64 * UWSPR_NSYM];    // [hyp][162]
+  const int lane = threadIdx.x;
+  const int h0 = blockIdx.x * 64;
+  const int nh = min(64, H - h0);
+  const int h = h0 + min(lane, nh - 1);
+  const bool live = lane < nh && hyps[h].frame >= 0;
   const bool soft = symbols != nullptr;
-#pragma unroll 6
-  for (int i = 0; i < UWSPR_NSYM; i++) {
-    const float4 P = ph[i];
-    const bool bit = pr3_rt(i);
-    totp = totp + P.x; totp = totp + P.y; totp = totp + P.z; totp = totp + P.w;  // cc:213
-    const float cmet = (P.y + P.w) - (P.x + P.z);                               // cc:214
-    ss = bit ? ss + cmet : ss - cmet;                                           // cc:215
-    if (soft) {
-      const float fs = bit ? P.w - P.y : P.z - P.x;                             // cc:219,222
-      fsum = (float)((double)fsum + (double)fs / 162.0);                        // cc:243
-      f2sum = (float)((double)f2sum + (double)(fs * fs) / 162.0);               // cc:244
+  const float4 *base = p + (size_t)h0 * UWSPR_NSYM;
+
+  auto stage = [&](int c) {   // chunk c of the 64 rows -> tile
+    k5_wave_fence();
+#pragma unroll
+    for (int j = 0; j < K5L_CH; j++) {
+      const int idx = lane + 64 * j;                 // 0..575: hyp = idx / 9, sym = idx % 9
+      const int hy = idx / K5L_CH, sy = idx - hy * K5L_CH;
+      tile[idx] = base[(size_t)min(hy, nh - 1) * UWSPR_NSYM + c * K5L_CH + sy];
+    }
+    k5_wave_fence();
+  };
+
+  float ss = 0.0f, totp = 0.0f, fsum = 0.0f, f2sum = 0.0f;
+  for (int c = 0; c < UWSPR_NSYM / K5L_CH; c++) {
+    stage(c);
+#pragma unroll
+    for (int j = 0; j < K5L_CH; j++) {
+      const float4 P = tile[lane * K5L_CH + j];
+      const bool bit = pr3_rt(c * K5L_CH + j);
+      totp = totp + P.x; totp = totp + P.y; totp = totp + P.z; totp = totp + P.w;  // cc:213
+      const float cmet = (P.y + P.w) - (P.x + P.z);                               // cc:214
+      ss = bit ? ss + cmet : ss - cmet;                                           // cc:215
+      if (soft) {
+        const float fs = bit ? P.w - P.y : P.z - P.x;                             // cc:219,222
+        fsum = (float)((double)fsum + (double)fs / 162.0);                        // cc:243
+        f2sum = (float)((double)f2sum + (double)(fs * fs) / 162.0);               // cc:244
+      }
     }
   }
-  sync[h] = ieee_divf(ss, totp);  // cc:226
-  if (soft) {
-    const float fac = ieee_sqrtf(f2sum - fsum * fsum);  // cc:246
-    uint8_t *out = symbols + (size_t)h * UWSPR_NSYM;
-    for (int i = 0; i < UWSPR_NSYM; i++) {
-      const float4 P = ph[i];
+  if (lane < nh) sync[h] = live ? ieee_divf(ss, totp) : -1e30f;  // cc:226
+  if (!soft) return;
+
+  const float fac = ieee_sqrtf(f2sum - fsum * fsum);  // cc:246
+  for (int c = 0; c < UWSPR_NSYM / K5L_CH; c++) {
+    stage(c);
+#pragma unroll
+    for (int j = 0; j < K5L_CH; j++) {
+      const float4 P = tile[lane * K5L_CH + j];
+      const int i = c * K5L_CH + j;
       const bool bit = pr3_rt(i);
       float v = bit ? P.w - P.y : P.z - P.x;
       v = ieee_divf(symfac * v, fac);  // cc:248
       if (v > 127.0f) v = 127.0f;
       if (v < -128.0f) v = -128.0f;
       v = v + 128.0f;
-      out[i] = (v != v) ? (uint8_t)0 : (uint8_t)(int)v;  // cc:251 (NaN defined as 0)
+      bytes[lane * UWSPR_NSYM + i] = (!live || v != v) ? (uint8_t)0 : (uint8_t)(int)v;  // cc:251 (NaN -> 0)
+    }
+  }
+  k5_wave_fence();
+  // 64 x 162 bytes are contiguous in the output: 4 bytes per lane and pass
+  uint8_t *out = symbols + (size_t)h0 * UWSPR_NSYM;
+  const int nbytes = nh * UWSPR_NSYM;
+  for (int o = 4 * lane; o < nbytes; o += 256) {
+    if (o + 4 <= nbytes && ((reinterpret_cast<uintptr_t>(out) + o) & 3) == 0) {
+      *reinterpret_cast<uint32_t *>(out + o) = *reinterpret_cast<const uint32_t *>(&bytes[o]);
+    } else {
+      for (int q = 0; q < 4 && o + q < nbytes; q++) out[o + q] = bytes[o + q];
     }
   }
 }
@@ -76,11 +114,6 @@ __global__ __launch_bounds__(256) void k5_fold(const dev_hyp *__restrict__ hyps,
 // serial: lane 0 adds the 648 magnitudes (cc:213), lane 1 the 162 signed
 // metrics (cc:215), lanes 2/3 the binary64-stepped fsum / f2sum (cc:243-244).
 constexpr int K5W_WAVES = 4;
-__device__ __forceinline__ void k5_wave_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 struct k5_wave_lds {
   float4 str[2][UWSPR_NSYM];   // [0]: magnitudes, [1]: (0,0,0,+-cmet)
@@ -173,13 +206,15 @@ void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, floa
                  uint8_t *symbols) {
   if (H <= 0) return;
   prof_scope ps(c, UWSPR_K_FOLD, H);
-  static const bool lanes_form = getenv("UWSPR_K5_LANES") && atoi(getenv("UWSPR_K5_LANES")) != 0;
+  // lanes form from 32768 hypotheses up (UWSPR_K5_LANES=0/1 forces one or the other)
+  static const int forced = getenv("UWSPR_K5_LANES") ? atoi(getenv("UWSPR_K5_LANES")) : -1;
+  const bool lanes_form = forced >= 0 ? forced != 0 : H >= 32768;
   if (!lanes_form) {
     dim3 g((H + K5W_WAVES - 1) / K5W_WAVES), b(64 * K5W_WAVES);
     if (symbols) hipLaunchKernelGGL(k5_fold_wave<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
     else hipLaunchKernelGGL(k5_fold_wave<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
   } else {
-    hipLaunchKernelGGL(k5_fold, dim3((H + 255) / 256), dim3(256), 0, c->stream, hyps, p, H, 50.0f,
+    hipLaunchKernelGGL(k5_fold, dim3((H + 63) / 64), dim3(64), 0, c->stream, hyps, p, H, 50.0f,
                        sync, symbols);
   }
 }
