@@ -561,11 +561,21 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
       *reinterpret_cast<float2 *>(&lds[(4 * j + segq) * RS + 2 * kk + 32 * pos]) = stage[j];
   };
 
-  // prologue: slots 0..Q
+  // prologue: slots 0..Q -- all their loads in flight together (one memory round trip, not Q+1)
+  {
+    float2 pro[Q + 1][4];
 #pragma unroll
-  for (int sl = 0; sl <= Q; sl++) {
-    load_slot(sl);
-    store_slot(sl);
+    for (int sl = 0; sl <= Q; sl++) {
+      load_slot(sl);
+#pragma unroll
+      for (int j = 0; j < 4; j++) pro[sl][j] = stage[j];
+    }
+#pragma unroll
+    for (int sl = 0; sl <= Q; sl++) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) stage[j] = pro[sl][j];
+      store_slot(sl);
+    }
   }
 
   // ring positions of slots c..c+Q as this lane's row addresses
