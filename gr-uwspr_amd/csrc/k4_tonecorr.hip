@@ -520,10 +520,14 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
       fp = gy.f0 + gy.slmc;
     }
     const float delta = ((float)tone - 1.5f) * 1.46484375f;
+#if defined(K4R_EXP) && (K4R_EXP & 4)   // timing experiment 4: no binary64 sincos
+    cd = 0.999f + 1e-6f * fp; sd = 0.01f + delta * 1e-6f;
+#else
     double sn, cs;
     sincos(kTwoPiDt * (double)(fp + delta), &sn, &cs);
     cd = (float)cs;
     sd = (float)sn;
+#endif
   }
 
   // ---- cooperative loader: load j of a slot = pair 4j + lane/16, sample lane%16
@@ -562,6 +566,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   };
 
   // prologue: slots 0..Q -- all their loads in flight together (one memory round trip, not Q+1)
+#if !(defined(K4R_EXP) && (K4R_EXP & 8))   // timing experiment 8: no prologue loads
   {
     float2 pro[Q + 1][4];
 #pragma unroll
@@ -577,6 +582,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
       store_slot(sl);
     }
   }
+#endif
 
   // ring positions of slots c..c+Q as this lane's row addresses
   int sa[M];   // dword offsets into `lds` (kept as integers so the reads stay ds_read)
@@ -623,7 +629,10 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
             vn[l] = *reinterpret_cast<const float4 *>(&lds[sa[o >> 4] + 2 * (o & 15)]);
           }
         }
-        __builtin_amdgcn_sched_barrier(0);
+        // S5's three groups per candidate fill the chip: pin the reads ahead (86 VGPRs, 4 waves per
+        // SIMD); S3 has 2-3 waves per SIMD whatever its register count, and left to the scheduler
+        // (143 VGPRs) it ran 7 % faster
+        if (NL != 5) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int half = 0; half < 2; half++) {
 #pragma unroll
