@@ -629,10 +629,8 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
             vn[l] = *reinterpret_cast<const float4 *>(&lds[sa[o >> 4] + 2 * (o & 15)]);
           }
         }
-        // S5's three groups per candidate fill the chip: pin the reads ahead (86 VGPRs, 4 waves per
-        // SIMD); S3 has 2-3 waves per SIMD whatever its register count, and left to the scheduler
-        // (143 VGPRs) it ran 7 % faster
-        if (NL != 5) __builtin_amdgcn_sched_barrier(0);
+        // (pinning these reads ahead with sched_barrier -- 86 VGPRs instead of ~145 -- was 7 % slower
+        // for S3 and 1 % slower for S5 under three streams: left to the scheduler)
 #pragma unroll
         for (int half = 0; half < 2; half++) {
 #pragma unroll
