@@ -239,7 +239,9 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
         offw[((size_t)r * f.umax + u) * 41 + k4] = v;
       }
     }
-  f.uoff_global = 0;
+  // The offset sequences are read from HBM/L2 by default: 31 KB less LDS per workgroup lets other
+  // streams' kernels share the CU (+3 % under three streams); UWSPR_K3_UOFF_GLOBAL=0 stages them in LDS
+  f.uoff_global = (getenv("UWSPR_K3_UOFF_GLOBAL") && atoi(getenv("UWSPR_K3_UOFF_GLOBAL")) == 0) ? 0 : 1;
   if (coarse_lds_bytes(f) > 160 * 1024) f.uoff_global = 1;   // keep the offset sequences out of LDS
   if (coarse_lds_bytes(f) > 160 * 1024)
     return fail(c, UWSPR_ERR_UNSUPPORTED, "coarse search needs %zu B of LDS (> 160 KiB): reduce maxdrift/cf",
