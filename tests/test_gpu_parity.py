@@ -555,3 +555,31 @@ def test_other_carrier_and_frame_parameters(G, oracle):
                         assert np.float32(o[k]).tobytes() == np.float32(d[k]).tobytes(), (kw, b, j, k)
                     if d["worth_a_try"]:
                         assert (o["symbols"] == d["symbols"]).all(), (kw, b, j)
+
+
+def test_coarse_search_offset_table_in_lds_or_hbm(G, frames, monkeypatch):
+    """K3 reads the deduplicated offset sequences from HBM/L2 by default and from an LDS
+    copy with UWSPR_K3_UOFF_GLOBAL=0: identical candidates and identical 16 380 metrics."""
+    res = []
+    for v in ("1", "0"):
+        monkeypatch.setenv("UWSPR_K3_UOFF_GLOBAL", v)
+        c = G.Context()
+        try:
+            c.keep_syncgrid(2)
+            cands = c.fdr_batch(frames)
+            grid = c.fdr_syncgrid(len(frames))
+        finally:
+            c.close()
+        res.append((cands, grid))
+    (ca, ga), (cb, gb) = res
+    for b in range(len(frames)):
+        assert len(ca[b]) == len(cb[b]) >= 1
+        for j, (x, y) in enumerate(zip(ca[b], cb[b])):
+            for k in ("m_type", "freq", "snr", "sync", "shift"):
+                assert x[k].tobytes() == y[k].tobytes(), (b, j, k)
+            if int(x["m_type"]) == 1:
+                assert all(x[k] == y[k] for k in ("V1", "V2", "p1", "p2"))
+            else:
+                assert x.tobytes()[24:28] == y.tobytes()[24:28]
+            if j < 2:
+                assert ga[b, j].tobytes() == gb[b, j].tobytes()
