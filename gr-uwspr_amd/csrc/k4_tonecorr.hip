@@ -312,6 +312,21 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
   }
   const bool interior = __all(inside);
 
+  // One-symbol wrap (S0: lags shift-128 .. shift+128): when the last lag is exactly one symbol
+  // (256 samples) after the first and the per-symbol frequency does not depend on the symbol,
+  // symbol i at the last lag reads the samples of symbol i+1 at the first lag against the same
+  // phasors -- the same numbers.  Such a group correlates NL-1 lags; the lane of symbol i+1
+  // stores its first-lag result for (last lag, symbol i) as well.  Only the wavefront that holds
+  // symbol 161 (no successor) walks all NL lags.
+  auto wraps = [&](const dev_grp &g, bool ok) {
+    return NL == 5 && ok && (g.nvalid & 0xff) == NL && g.lag[NL - 1] - g.lag[0] == 256 &&
+           (g.m_type != UWSPR_LINEAR || g.drift == 0.0f);
+  };
+  const bool wrapA = wraps(A, okA), wrapB = wraps(Bg, okB);
+  const bool hasB = sb < PPW;
+  const bool all_lags = (okA && !wrapA) || (hasB && okB && !wrapB) ||
+                        (okA && iA0 + sb - 1 >= UWSPR_NSYM - 1);   // wave-uniform
+
   // ---- this lane's tone phasor step (binary64 angle, cc:173-189) ------------
   float cd, sd;
   {
@@ -348,16 +363,24 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
 
   const bool fast = interior && near;  // wave-uniform
   float2 stage[NLD];
+  float c = 1.0f, s = 0.0f;
+  float inp[NL], quad[NL];
+#pragma unroll
+  for (int l = 0; l < NL; l++) { inp[l] = 0.0f; quad[l] = 0.0f; }
+
+  auto walk = [&](auto nlw_tag) {
+  constexpr int NLW = decltype(nlw_tag)::value;   // lags this wavefront walks (NL, or NL-1 with the wrap)
+  constexpr int NLDW = 4 * NLW;
   auto load_chunk = [&](int c) {
     if (fast) {
 #pragma unroll
-      for (int t = 0; t < NLD; t++) {
+      for (int t = 0; t < NLDW; t++) {
         const int l = t >> 2, j = t & 3;
         stage[t] = wbase[eoff[j] + (slotA[j] ? la[l] : lb[l]) + 16 * c];
       }
     } else {
 #pragma unroll
-      for (int t = 0; t < NLD; t++) {
+      for (int t = 0; t < NLDW; t++) {
         const int l = t >> 2, j = t & 3;
         const int lag = slotA[j] ? la[l] : lb[l];
         const int n = (slotA[j] ? 256 * (iA0 + 4 * j + segq) : 256 * (4 * j + segq - sb)) + kk + lag + 16 * c;
@@ -369,17 +392,12 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
     }
   };
 
-  float c = 1.0f, s = 0.0f;
-  float inp[NL], quad[NL];
-#pragma unroll
-  for (int l = 0; l < NL; l++) { inp[l] = 0.0f; quad[l] = 0.0f; }
-
   K4_STAMP(1);
   load_chunk(0);
   for (int ch = 0; ch < 16; ch++) {
     wave_lds_fence();
 #pragma unroll
-    for (int t = 0; t < NLD; t++) {
+    for (int t = 0; t < NLDW; t++) {
       const int l = t >> 2, j = t & 3;
       *reinterpret_cast<float2 *>(&lds[(4 * j + segq) * ROWDW + (kk * NLP + l) * 2]) = stage[t];
     }
@@ -390,8 +408,8 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
     auto read_slot = [&](int k, float2 (&x)[NLP]) {
       const float *slot = &lds[pr * ROWDW + k * NLP * 2];
 #pragma unroll
-      for (int q = 0; q < NLP / 2; q++) {
-        if (2 * q + 1 < NL || (NL & 1) == 0) {
+      for (int q = 0; q < (NLW + 1) / 2; q++) {
+        if (2 * q + 1 < NLW) {
           const float4 v = *reinterpret_cast<const float4 *>(slot + 4 * q);
           x[2 * q] = make_float2(v.x, v.y); x[2 * q + 1] = make_float2(v.z, v.w);
         } else {
@@ -400,12 +418,14 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
       }
     };
     float2 xc[NLP], xn[NLP];
+#pragma unroll
+    for (int l = 0; l < NLP; l++) { xc[l] = make_float2(0.0f, 0.0f); xn[l] = xc[l]; }
     read_slot(0, xc);
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       if (k < 15) read_slot(k + 1, xn);
 #pragma unroll
-      for (int l = 0; l < NL; l++) {
+      for (int l = 0; l < NLW; l++) {
         inp[l] = (inp[l] + xc[l].x * c) + xc[l].y * s;     // cc:206
         quad[l] = (quad[l] - xc[l].x * s) + xc[l].y * c;   // cc:207
       }
@@ -416,17 +436,24 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
       for (int l = 0; l < NLP; l++) xc[l] = xn[l];
     }
   }
+  };   // walk
+  if (all_lags) walk(std::integral_constant<int, NL>{});
+  else walk(std::integral_constant<int, (NL == 5 ? NL - 1 : NL)>{});
 
   K4_STAMP(2);
   if (g0 + pr < total) {
     const int nv = mineA ? nvA : nvB;
     const int hb = mineA ? A.hyp_base : Bg.hyp_base;
     const uint32_t hm = mineA ? A.hmap : Bg.hmap;
+    const bool wrap = mineA ? wrapA : wrapB;
 #pragma unroll
     for (int l = 0; l < NL; l++) {
-      if (l < nv) {
+      if (l < nv && (all_lags || l < NL - 1 || NL != 5)) {
         const float pj = ieee_sqrtf(inp[l] * inp[l] + quad[l] * quad[l]);  // cc:211
         p_out[((long long)(hb + (int)((hm >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = pj;
+        // the wrap: (first lag, symbol i) is also (last lag, symbol i-1)
+        if (NL == 5 && l == 0 && wrap && own_i >= 1)
+          p_out[((long long)(hb + (int)((hm >> (4 * (NL - 1))) & 15u)) * UWSPR_NSYM + own_i - 1) * 4 + tone] = pj;
       }
     }
     // groups that are skipped produce zeros for their hypotheses
