@@ -7,8 +7,9 @@
  * lib/metric_tables.c) and lib/helpers.cc.  oracle/Makefile compiles those
  * files WHERE THEY LIE under /root/reference and links them with this shim
  * into oracle/_ref/libuwspr_ref.so.  Nothing of the reference is copied into
- * this repository; the .so is git-ignored and only travels to the GPU box as
- * a built artefact.
+ * this repository; the .so is git-ignored AND gpurun-ignored: objects built from
+ * the reference never leave this container; GPU-side tests read the
+ * committed fixtures under tests/golden/ that were generated through it.
  *
  * lib/FDR_impl.cc and lib/sync_and_demodulate_impl.cc are NOT buildable here
  * (they need gnuradio/pmt/boost/fftw3/volk headers and libraries that this
