@@ -110,8 +110,12 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->reuse_centre = !(getenv("UWSPR_K4_REUSE") && atoi(getenv("UWSPR_K4_REUSE")) == 0);
   // frequency/drift stages through the grid form: parity-tested but measured 9 % SLOWER than the
   // flat kernel at 5 hypotheses per candidate (4 waves/SIMD, window loads not overlapped): opt-in
+  c->use_fused = !(getenv("UWSPR_SCHED_FUSED") && atoi(getenv("UWSPR_SCHED_FUSED")) == 0);
+  c->sched_nopad = getenv("UWSPR_SCHED_NOPAD") && atoi(getenv("UWSPR_SCHED_NOPAD")) != 0;
   c->use_stage_grid = getenv("UWSPR_K4_STAGE_GRID") && atoi(getenv("UWSPR_K4_STAGE_GRID")) != 0;
   c->cap_slab = 0; c->d_slab = nullptr;
+  c->sched_grid = getenv("UWSPR_SCHED_GRID") ? atoi(getenv("UWSPR_SCHED_GRID")) : 0;
+  c->cap_tabs = 0; c->d_tabs = nullptr; c->d_counter = nullptr;
   *out = c;  // handed back even on failure so uwspr_last_error() can be read
 
   fdr_consts &f = c->fc;
@@ -263,7 +267,7 @@ extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
   void *bufs[] = {c->d_window, c->d_twiddle, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
                   c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_cent,
-                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab};
+                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter};
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (auto &e : c->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -638,6 +642,17 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
   const size_t nslots = (size_t)B * per_frame;
   int rc;
   if ((rc = ensure(c, &c->d_state, &c->cap_state, nslots))) return rc;
+  if (c->use_fused) {
+    // k6_sched: one workgroup per candidate, S0..S5 back to back
+    if (c->sched_grid <= 0) c->sched_grid = 2 * c->num_cus;
+    if ((rc = ensure(c, &c->d_tabs, &c->cap_tabs, (size_t)c->sched_grid * kSchedTabFloats))) return rc;
+    if (!c->d_counter) HIPCHK(c, hipMalloc((void **)&c->d_counter, 64));
+    if ((rc = ensure(c, &c->d_dout, &c->cap_dout, nslots))) return rc;
+    c->cur_dout = user_out ? user_out : c->d_dout;
+    launch_sched_fused(c, dframes, B, dcands, dnpk, cand_stride, per_frame, c->cur_dout, UWSPR_NJIG);
+    HIPCHK(c, hipGetLastError());
+    return UWSPR_OK;
+  }
   if ((rc = ensure(c, &c->d_hyps, &c->cap_hyps, 2 * nslots * UWSPR_NJIG))) return rc;
   if ((rc = ensure(c, &c->d_grps, &c->cap_grps, 3 * nslots))) return rc;
   // centres (48 B) followed by their frame indices (4 B): 13 int32 per slot in one buffer

@@ -142,6 +142,10 @@ struct uwspr_ctx {
   bool use_fstage;       // S1/S4 through the frequency-stage form (UWSPR_K4_FSTAGE=0: flat kernel)
   bool reuse_centre;     // skip the stage-winner hypothesis in S1/S3/S4 (UWSPR_K4_REUSE=0: recompute it)
   bool use_lag_ring;     // S3/S5 groups through the LDS-ring form (UWSPR_K4_RING=0: plain groups)
+  // fused schedule (k6_sched: one workgroup per candidate runs S0..S5; UWSPR_SCHED_FUSED=0: staged launches)
+  bool use_fused; bool sched_nopad; int sched_grid;
+  size_t cap_tabs; float *d_tabs;     // [sched_grid][2][5][4][256](c, s) phasor tables
+  int *d_counter;                     // candidate queue head of the running launch
   size_t cap_slab; uint8_t *d_slab;
 
   int prof_mask;
@@ -183,6 +187,11 @@ void launch_fold_step(uwspr_ctx *c, int stage, int ncand);
 void launch_pack_slabs(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t *npk,
                        const uwspr_demod_out *dout, int per_frame, int K, uint8_t *slab, int B);
 void launch_sched_finish(uwspr_ctx *c, int ncand);
+// the whole schedule in one launch (k6_sched.hip); njig = mode-2 tries to produce (17 = all)
+void launch_sched_fused(uwspr_ctx *c, const float *frames, int B, const uwspr_candidate *cands,
+                        const int32_t *npk, int cand_stride, int per_frame, uwspr_demod_out *out,
+                        int njig);
+constexpr int kSchedTabFloats = 2 * 5 * 4 * 512;   // per resident workgroup
 
 // profiling brackets
 struct prof_scope {
