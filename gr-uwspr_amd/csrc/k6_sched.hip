@@ -5,23 +5,27 @@
 //
 // The candidates of a batch are independent (cc:389 loops over them) and every
 // stage of a candidate needs all of the previous stage's 162 symbols, so the
-// natural unit is: one 12-wavefront workgroup = one candidate, running
+// natural unit is: one 16-wavefront workgroup = one candidate, running
 // S0 -> S5 back to back with no kernel boundary, no tone magnitudes in HBM and
 // no cross-workgroup traffic.  (The staged form -- k4_* + k5_fold_step, 17
 // launches per batch -- stays as UWSPR_SCHED_FUSED=0; both give the same bytes.)
 //
-// Mapping.  Wavefront w works on tone (w & 3) of the 54 symbols 54 (w >> 2) ..;
-// a lane owns ONE symbol window ("row") and accumulates inp/quad for all the
-// hypotheses of the stage against it, every accumulator seeing exactly the
-// reference's sequence of binary32 operations (cc:206-207: no FMA, no tree).
+// Mapping.  A lane owns a symbol window ("row") and ONE tone, and accumulates
+// inp/quad for several hypotheses of the stage against it, every accumulator
+// seeing exactly the reference's sequence of binary32 operations (cc:206-207: no
+// FMA, no tree).  Sixteen wavefronts = four per SIMD (three per SIMD issue at 0.38
+// instructions per cycle on gfx950, two or four at 0.5: tools/op_probe.hip):
+// wavefront w has tone w & 3 and hypothesis slot w >> 2; a lane owns THREE rows (symbols lane,
+// 54 + lane, 108 + lane) and every slot carries a quarter of the stage's hypotheses
+// (k6_geom::slot_mask), so that each phasor run is fetched by exactly one wavefront.
 //  * Samples: the stage streams the rows [L0 + 256 i, L0 + 256 i + 256 + span)
 //    through a double-buffered LDS image, 16 samples per row and chunk, loaded
 //    cooperatively with coalesced 8-byte loads (cc:205's n > 0 && n < np test is
 //    applied by the loader: a skipped sample is a zero, which leaves inp/quad
-//    unchanged).  A lane reads its 16 samples once per chunk (8 ds_read_b128)
-//    and uses them for every hypothesis: a hypothesis whose lag is L0 + D sees
-//    stream position a as its sample k = a - D ("sample-major" order), so lag
-//    sweeps cost no extra loads -- S5's 17 lags are one pass over 384 samples.
+//    unchanged).  A lane reads its samples once per chunk and uses them for every
+//    hypothesis: a hypothesis whose lag is L0 + D sees stream position a as its
+//    sample k = a - D ("sample-major" order), so lag sweeps cost no extra loads --
+//    S5's 17 lags are one pass over 384 samples.
 //  * Phasors.  When the per-symbol frequency does not depend on the symbol
 //    (drift == 0 or the straight-line model with t = 0: the reference's `fplast`
 //    cache hits for the same reason, cc:185) the sequence c[k], s[k] of cc:186-199
@@ -33,15 +37,18 @@
 //    (f1 + {-2..2} 0.25 Hz) serves S0 and S1, set B (f1 + {-2..2} 0.05 Hz) S3, S4, S5.
 //    With a per-symbol frequency (a drifting linear model: always in S2) every lane
 //    runs its own recurrences, 14 operations per sample and hypothesis.
-//  * Fold (cc:213-226, 240-254) from LDS by up to six wavefronts, the order-sensitive
-//    running sums on single lanes as in k5_fold_wave; stage transitions (cc:227-231,
-//    416-452) by one thread; the stage winner's tone magnitudes are kept (2.6 KB) so
-//    that the hypothesis a later stage repeats -- the middle one of S1/S3/S4 and the
-//    first jiggered shift of S5 -- is not computed again.
+//  * Fold (cc:213-226, 240-254) from LDS: the per-symbol terms by all threads, then
+//    the order-sensitive running sums (totp, ss, fsum, f2sum, rms) one hypothesis per
+//    LANE, one kind of sum per wavefront; stage transitions (cc:227-231, 416-452) by
+//    one thread; the stage winner's tone magnitudes are kept (2.6 KB) so that the
+//    hypothesis a later stage repeats -- the middle one of S1/S3/S4 and the first
+//    jiggered shift of S5 -- is not computed again.
 //  * S0's last lag is one symbol after its first: (last lag, symbol i) is (first
 //    lag, symbol i+1) when the frequency does not depend on the symbol; a 163rd
 //    "virtual" row on an otherwise idle lane supplies (last lag, symbol 161).
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "uwspr_internal.h"
 
@@ -49,15 +56,17 @@
 
 namespace uwspr {
 
-constexpr int K6_WAVES = 12;
+constexpr int K6_WAVES = 16;
 constexpr int K6_THREADS = 64 * K6_WAVES;
-constexpr int K6_TROWS = 54;                  // rows per wavefront: 162 = 3 x 54
+
+constexpr int K6_TROWS = 54;                  // rows per row-role wavefront: 162 = 3 x 54
 constexpr int K6_MAXROWS = UWSPR_NSYM + 1;    // + the virtual row of the S0 wrap
 constexpr int K6_ROWDW = 36;                  // dwords per staged row: 16 samples x 8 B + 16 B pad
 constexpr int K6_NTAB = 5;                    // frequencies per table set
 constexpr int K6_TABSET = K6_NTAB * 4 * 512;  // floats per table set: [freq][tone][256](c, s)
-constexpr int K6_FOLDW = 6;                   // wavefronts that fold concurrently
 constexpr int K6_PSLAB = K6_MAXROWS * 4;      // floats per hypothesis in the p image
+constexpr int K6_FOLDH = 9;                   // hypotheses folded per round
+constexpr int K6_CMS = UWSPR_NSYM + 2;        // stride of the per-hypothesis scratch rows
 
 constexpr double kTwoPiDt6 = 2.0 * 3.14159265358979323846 * (double)(float)(1.0 / 375.0);  // cc:146,188
 
@@ -66,12 +75,23 @@ __device__ __forceinline__ bool pr3_6(int i) { return (kPr3_6[i >> 5] >> (i & 31
 
 typedef float f16v __attribute__((ext_vector_type(16)));
 #define K6_CONST __attribute__((address_space(4)))
+// The passes and folds are real (not inlined) functions -- each gets its own register allocation
+// instead of one 40 000-instruction body -- so LDS pointers cross the call as address-space-3
+// pointers and stay ds_read / ds_write inside.
+#define K6_LDS __attribute__((address_space(3)))
+#define K6_GLOBAL __attribute__((address_space(1)))
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef K6_LDS float lds_f;
+typedef K6_LDS v4f lds_f4;
+typedef K6_LDS v2f lds_f2;
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ void k6_wave_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+template <typename T>
+__device__ __forceinline__ T *uni_ptr(T *p) {   // a pointer that crossed a call: back into SGPRs
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = (unsigned)uni((int)(unsigned)v), hi = (unsigned)uni((int)(unsigned)(v >> 32));
+  return (T *)(((unsigned long long)hi << 32) | lo);
 }
 
 // slmFrequencyDrift(m_nl, cf, t = 0), lib/slm.cc:36-73, in binary64 like the reference (`t` is
@@ -85,11 +105,6 @@ static __device__ float k6_slm_drift_t0(double V1, double V2, int p1, int p2, fl
   return (float)((double)(-sign) * num / den * (double)cf / (double)1500.0f);
 }
 
-struct k6_scr {                 // per folding wavefront
-  float cm[UWSPR_NSYM + 2];     // signed cmet per symbol (cc:214-215); later (symbol - 128) for the rms
-  double q[2][UWSPR_NSYM];      // fs/162, fs*fs/162 (cc:243-244)
-};
-
 struct k6_args {
   const float2 *frames; int fl; int nframes;
   const uwspr_candidate *cands; const int32_t *npk; int cand_stride; int per_frame; int nslots;
@@ -100,6 +115,7 @@ struct k6_args {
   uwspr_demod_out *out;
   cand_state *state;            // [nslots] final state (resume / diagnostics)
   float *pwin;                  // [nslots][162][4] winner magnitudes (resume), or null
+  unsigned long long *stamps;   // diagnostics: [nslots][64] wall-clock ticks at the phase boundaries, or null
 };
 
 // ---- one pass over the sample stream -----------------------------------------------------------
@@ -110,6 +126,22 @@ enum { K6_S0 = 0, K6_S1 = 1, K6_S2 = 2, K6_S3 = 3, K6_S4 = 4, K6_S5 = 5 };
 template <int KIND> struct k6_geom {
   static constexpr int HMAX = KIND == K6_S2 ? 2 : KIND == K6_S5 ? UWSPR_NJIG : 5;
   static constexpr bool LAGS = KIND == K6_S0 || KIND == K6_S3 || KIND == K6_S5;   // one frequency, several lags
+  // Work split: wavefront w has tone w & 3 and hypothesis slot w >> 2; slot_mask(s) = the stage's
+  // hypotheses of slot s, row_mask(s, h) = which of the lane's three rows (symbols lane, 54 + lane,
+  // 108 + lane) it walks for them.  A stage of four computed hypotheses is one per slot; S5's
+  // sixteen are four per slot, dealt so that every slot has an early, two middle and a late lag
+  // (a lag is walked only while the stream position is inside its window); S2's two are split by rows so that three slots carry two
+  // (row, hypothesis) pairs each.  Hypotheses that are usually known (the middle one of S1/S3/S4,
+  // try 0 of S5, the wrapped last lag of S0) ride on a slot as an extra.
+  __host__ __device__ static constexpr uint32_t slot_mask(int s) {
+    return KIND == K6_S0 ? (s == 3 ? 0x18u : 1u << s)
+         : KIND == K6_S2 ? (s == 0 ? 0x1u : s == 1 ? 0x2u : s == 2 ? 0x3u : 0u)
+         : KIND == K6_S5 ? (s == 0 ? 0x08485u : s == 1 ? 0x03030u : s == 2 ? 0x04848u : 0x10302u)
+         : (s == 0 ? 0x05u : s == 1 ? 0x02u : s == 2 ? 0x08u : 0x10u);
+  }
+  __host__ __device__ static constexpr uint32_t row_mask(int s, int h) {
+    return KIND == K6_S2 ? (s == 2 ? 0x4u : 0x3u) : 0x7u;
+  }
   __host__ __device__ static constexpr int dk8(int h) {
     return KIND == K6_S0 ? 8 * h                                            // shift1 - 128 + 64 h  (cc:409-411)
          : KIND == K6_S3 ? 2 * h                                            // shift1 - 32 + 16 h   (cc:444)
@@ -118,209 +150,342 @@ template <int KIND> struct k6_geom {
   }
 };
 
+// index of the n-th set bit of M (compile time)
+template <uint32_t M>
+__host__ __device__ constexpr int nth_bit(int n) {
+  int c = 0;
+  for (int b = 0; b < 32; b++)
+    if ((M >> b) & 1u) { if (c == n) return b; c++; }
+  return 0;
+}
+
 // bit h of `mask` = hypothesis h is computed; tq0 = table of a lag sweep (LAGS); S1/S4 use table h.
 template <int KIND, bool TAB>
-__device__ __forceinline__ void k6_pass(const float2 *__restrict__ fb, int fl, int L0, int nrows,
-                                        int nchunks, uint32_t mask, int tq0, float fc, float fstep,
-                                        float drp, float drm, int m_type, float slmc,
-                                        const float *tabset, float *stage) {
+__device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int fl, int L0, int nrows,
+                                     int nchunks, uint32_t mask, int tq0, float fc, float fstep,
+                                     float drp, float drm, int m_type, float slmc,
+                                     const float *tabset, lds_f *stage, unsigned long long *cst = nullptr) {
+  // cst (diagnostics, S1 only): wall-clock ticks of wavefront 0 at the start of every chunk
   using G = k6_geom<KIND>;
   constexpr int HMAX = G::HMAX;
   constexpr bool SHARED = G::LAGS;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = uni(tid >> 6);
-  const int tone = wv & 3, third = wv >> 2;
-  // lanes 0..53: the wave's symbols; lane 54 of the last third: the virtual row (nrows == 163)
-  int row = K6_TROWS * third + lane;
-  const bool has_row = (lane < K6_TROWS) || (third == 2 && lane == K6_TROWS && nrows > UWSPR_NSYM);
-  if (!has_row) row = K6_TROWS * third;   // idle lanes shadow a real row (results discarded)
+  // arguments are workgroup-uniform; across the call they arrive in VGPRs
+  // (and as generic pointers: the frame is read with global_load, not flat_load -- a flat load
+  // counts as an LDS access too and would tie every LDS / scalar wait to HBM latency)
+  const K6_GLOBAL v2f *fbg = (const K6_GLOBAL v2f *)uni_ptr(fb);
+  tabset = uni_ptr(tabset);
+  fl = uni(fl); L0 = uni(L0); nrows = uni(nrows); nchunks = uni(nchunks); mask = (uint32_t)uni((int)mask);
+  tq0 = uni(tq0); m_type = uni(m_type);
 
-  // ---- loader: element e = tid + 768 n -> row tid / 16 + 48 n, sample tid % 16
+  // ---- loader: element e = tid + 1024 n -> row tid / 16 + 64 n, sample tid % 16
   const int lr = tid >> 4, lj = tid & 15;
   const int sbase = lr * K6_ROWDW + 2 * lj;
   const bool interior = (L0 > 0) && (L0 + 256 * (nrows - 1) + 16 * nchunks < fl);   // workgroup-uniform
-  float2 greg[4];
-  auto gload = [&](int c) {
+  // frame loads run TWO chunks ahead of the arithmetic (a load from the Infinity Cache / HBM takes
+  // longer than one chunk's arithmetic): two register sets, alternating by chunk parity
+  float2 gregs[2][3];
+  auto gload = [&](int c, auto par) {
+    float2 (&greg)[3] = gregs[decltype(par)::value];
+#if defined(K6_EXP) && (K6_EXP & 1)   // timing experiment: no global loads in the walk
+    for (int n = 0; n < 3; n++) greg[n] = make_float2(0.5f + (float)c, 0.25f);
+    if (c >= 0) return;
+#endif
     if (interior) {
 #pragma unroll
-      for (int n = 0; n < 4; n++) {
-        const int r = min(lr + 48 * n, nrows - 1);
-        greg[n] = fb[L0 + 256 * r + lj + 16 * c];
+      for (int n = 0; n < 3; n++) {
+        const int r = min(lr + 64 * n, nrows - 1);
+        const v2f v = fbg[L0 + 256 * r + lj + 16 * c];
+        greg[n] = make_float2(v.x, v.y);
       }
     } else {
 #pragma unroll
-      for (int n = 0; n < 4; n++) {
-        const int r = min(lr + 48 * n, nrows - 1);
+      for (int n = 0; n < 3; n++) {
+        const int r = min(lr + 64 * n, nrows - 1);
         const int ns = L0 + 256 * r + lj + 16 * c;
         const bool inr = (ns > 0) && (ns < fl);                 // cc:205, sample 0 excluded
-        const float2 v = fb[min(max(ns, 0), fl - 1)];
-        greg[n] = inr ? v : make_float2(0.0f, 0.0f);
+        const v2f v = fbg[min(max(ns, 0), fl - 1)];
+        greg[n] = inr ? make_float2(v.x, v.y) : make_float2(0.0f, 0.0f);
       }
     }
   };
-  auto gstore = [&](int buf) {
+  auto gstore = [&](int buf, auto par) {   // chunk `buf`'s samples (loaded two chunks ago) into LDS buffer buf & 1
+    float2 (&greg)[3] = gregs[decltype(par)::value];
 #pragma unroll
-    for (int n = 0; n < 4; n++)
-      if (lr + 48 * n < nrows)
-        *reinterpret_cast<float2 *>(&stage[buf * K6_MAXROWS * K6_ROWDW + sbase + 48 * n * K6_ROWDW]) = greg[n];
+    for (int n = 0; n < 3; n++)
+      if (lr + 64 * n < nrows)
+        *(lds_f2 *)(&stage[(buf & 1) * K6_MAXROWS * K6_ROWDW + sbase + 64 * n * K6_ROWDW]) = v2f{greg[n].x, greg[n].y};
   };
 
-  float inp[HMAX], quad[HMAX];
-#pragma unroll
-  for (int h = 0; h < HMAX; h++) { inp[h] = 0.0f; quad[h] = 0.0f; }
+  // ---- the walk of one hypothesis slot: three rows per lane, the hypotheses of slot_mask(SLOT)
+  auto walk = [&](auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    constexpr uint32_t SM = G::slot_mask(SLOT);
+    constexpr int NR = 3;
+    const int tone = wv & 3;
+    // lanes 0..53: symbols lane, 54 + lane, 108 + lane; lane 54: the virtual row 162 (nrows == 163)
+    const bool virt = (lane == K6_TROWS) && (nrows > UWSPR_NSYM);
+    const int row0 = lane < K6_TROWS ? lane : 0;          // idle lanes shadow real rows (results discarded)
 
-  // per-lane path: phasor steps from this lane's symbol frequency (cc:170-189)
-  constexpr int NPH = TAB ? 1 : HMAX;
-  constexpr int NST = TAB ? 1 : (SHARED ? 1 : HMAX);
-  float pc[NPH], psn[NPH], cd[NST], sd[NST];
-  if (!TAB) {
-    const float delta = ((float)tone - 1.5f) * 1.46484375f;          // cc:148
-    const int own_i = min(row, UWSPR_NSYM - 1);
+    float inp[NR][HMAX], quad[NR][HMAX];
 #pragma unroll
-    for (int h = 0; h < NST; h++) {
-      const float f0 = (KIND == K6_S2 || SHARED) ? fc : fc + (float)(h - 2) * fstep;   // cc:164
-      const float dr = KIND == K6_S2 ? (h == 0 ? drp : drm) : drp;
-      float fp;
-      if (m_type == UWSPR_LINEAR)
-        fp = (float)((double)f0 + ((double)dr / 2.0) * ((double)(float)own_i - 81.0) / 81.0);  // cc:173
-      else
-        fp = f0 + slmc;                                               // cc:179 (t = 0)
-      double sn, cs;
-      sincos(kTwoPiDt6 * (double)(fp + delta), &sn, &cs);             // cc:188-189
-      cd[h] = (float)cs; sd[h] = (float)sn;
+    for (int r = 0; r < NR; r++)
+#pragma unroll
+      for (int h = 0; h < HMAX; h++) { inp[r][h] = 0.0f; quad[r][h] = 0.0f; }
+
+    // per-lane path: phasor steps from the row's symbol frequency (cc:170-189)
+    constexpr int NPH = TAB ? 1 : HMAX;
+    constexpr int NST = TAB ? 1 : (SHARED ? 1 : HMAX);
+    float pc[NR][NPH], psn[NR][NPH], cd[NR][NST], sd[NR][NST];
+    if (!TAB) {
+      const float delta = ((float)tone - 1.5f) * 1.46484375f;          // cc:148
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+        const int own_i = min(row0 + K6_TROWS * r, UWSPR_NSYM - 1);
+#pragma unroll
+        for (int h = 0; h < NST; h++) {
+          if (!SHARED && !((SM >> h) & 1u)) continue;
+          if (!SHARED && !((G::row_mask(SLOT, h) >> r) & 1u)) continue;
+          const float f0 = (KIND == K6_S2 || SHARED) ? fc : fc + (float)(h - 2) * fstep;   // cc:164
+          const float dr = KIND == K6_S2 ? (h == 0 ? drp : drm) : drp;
+          float fp;
+          if (m_type == UWSPR_LINEAR)
+            fp = (float)((double)f0 + ((double)dr / 2.0) * ((double)(float)own_i - 81.0) / 81.0);  // cc:173
+          else
+            fp = f0 + slmc;                                               // cc:179 (t = 0)
+          double sn, cs;
+          sincos(kTwoPiDt6 * (double)(fp + delta), &sn, &cs);             // cc:188-189
+          cd[r][h] = (float)cs; sd[r][h] = (float)sn;
+        }
+#pragma unroll
+        for (int h = 0; h < NPH; h++) { pc[r][h] = 1.0f; psn[r][h] = 0.0f; }
+      }
     }
-#pragma unroll
-    for (int h = 0; h < NPH; h++) { pc[h] = 1.0f; psn[h] = 0.0f; }
-  }
-  const K6_CONST float *tabw = (const K6_CONST float *)tabset + tone * 512 + (SHARED ? tq0 * 2048 : 0);
+    const K6_CONST float *tabw = (const K6_CONST float *)tabset + tone * 512 + (SHARED ? tq0 * 2048 : 0);
+    const uint32_t wmask = mask & SM;
+    // rows this slot reads at all (S2's third slot walks only the last row of each lane)
+    constexpr uint32_t ROWS = KIND == K6_S2 ? (SLOT == 2 ? 0x4u : SLOT == 3 ? 0u : 0x3u) : 0x7u;
 
-  gload(0);
-  gstore(0);
-  __syncthreads();
-  for (int c = 0; c < nchunks; c++) {
-    gload(min(c + 1, nchunks - 1));           // in flight during the arithmetic
-    const float *rowp = &stage[(c & 1) * K6_MAXROWS * K6_ROWDW + row * K6_ROWDW];
+    // ---- the chunk loop, software-pipelined by hand.
+    // All sixteen wavefronts leave every barrier together and would run in lockstep -- read
+    // samples, wait, multiply, read, wait, ... -- so that LDS / scalar-memory time and VALU time
+    // ADD instead of overlapping (tools/mix_probe.hip: 0.32 instructions per cycle and SIMD
+    // against 0.5).  Hence: the unit of work is a ROW-ITEM (one of the lane's rows, 8 steps, all
+    // hypotheses of the slot: 64 multiply-adds each); the samples of row-item t+1 are requested
+    // right after the wait that opens row-item t, and the phasor runs of the next half during
+    // the last row-item of this half, so everything a wait drains was issued a row-item earlier.
+    // (SMEM returns out of order: with a scalar load pending every wait is "all outstanding" --
+    // so waits come first, requests second, arithmetic third, by explicit ordering.)
+    constexpr int NI = __builtin_popcount(SM & ((1u << HMAX) - 1u));    // hypotheses of this slot
+    constexpr int NRI = __builtin_popcount(ROWS);                        // rows per half
+    constexpr bool DBL = NI <= 2;     // phasor runs double-buffered by half (else reloaded in place)
+    constexpr int NSET = DBL ? 2 : 1;
+    auto run_off = [&](int cc, int hf, int h) {   // dword offset (from tabw) of hypothesis h's run at (chunk, half)
+      const int k0 = 16 * cc + 8 * hf - 8 * G::dk8(h);
+      return uni((SHARED ? 0 : h * 2048) + 2 * min(max(k0, 0), 248));
+    };
+    f16v run[NSET][NI > 0 ? NI : 1];
+    if (TAB) {
 #pragma unroll
-    for (int half = 0; half < 2; half++) {
-      float4 xv[4];
+      for (int i = 0; i < NI; i++) run[0][i] = *(const K6_CONST f16v *)(tabw + run_off(0, 0, nth_bit<SM>(i)));
+    }
+    v4f xb[2][4];
+    auto issue_x = [&](v4f (&x)[4], int c, int half, int r) {
+      // lane 54 (virtual row): its third row is row 162 = 108 + 54
+      const lds_f *rp = &stage[(c & 1) * K6_MAXROWS * K6_ROWDW + ((virt ? K6_TROWS : row0) + r * K6_TROWS) * K6_ROWDW + 16 * half];
 #pragma unroll
-      for (int j = 0; j < 4; j++) xv[j] = *reinterpret_cast<const float4 *>(rowp + 16 * half + 4 * j);
+      for (int j = 0; j < 4; j++) x[j] = *(const lds_f4 *)(rp + 4 * j);
+    };
+
+    auto do_chunk = [&](int c, auto par) {   // par = c & 1 (the chunk loop is unrolled by two: static register sets)
+      constexpr int PAR = decltype(par)::value;
+      if (KIND == K6_S1 && cst && tid == 0) cst[c] = wall_clock64();
+      gload(min(c + 2, nchunks - 1), par);   // chunk c + 2 has the parity of chunk c; lands two chunks later
+      if (NRI > 0) issue_x(xb[0], c, 0, nth_bit<ROWS>(0));
 #pragma unroll
-      for (int h = 0; h < HMAX; h++) {
-        if (!((mask >> h) & 1u)) continue;                 // uniform
-        const int k0 = 16 * c + 8 * half - 8 * G::dk8(h);  // uniform: this hypothesis' first step
-        if (k0 < 0 || k0 > 248) continue;
-        if (TAB) {
-          const f16v ph = *(const K6_CONST f16v *)(tabw + (SHARED ? 0 : h * 2048) + 2 * k0);
+      for (int t = 0; t < 2 * NRI; t++) {
+        const int half = t / NRI, ri = t % NRI, r = nth_bit<ROWS>(ri);
+        const int set = DBL ? half : 0;
+        v4f (&x)[4] = xb[t & 1];
+        // ---- everything outstanding has landed: this row-item's samples, this half's runs
+        int tok = 0;
+        if (TAB && NI == 4)
+          asm volatile("; row-item ready" : "+s"(tok) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]),
+                       "s"(run[set][0]), "s"(run[set][NI > 1 ? 1 : 0]), "s"(run[set][NI > 2 ? 2 : 0]), "s"(run[set][NI > 3 ? 3 : 0]));
+        else if (TAB)
+          asm volatile("; row-item ready" : "+s"(tok) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]),
+                       "s"(run[set][0]), "s"(run[set][NI > 1 ? 1 : 0]));
+        else
+          asm volatile("; row-item ready" : "+s"(tok) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+        // ---- requests for the next row-item (tok ties them behind the wait)
+        if (t + 1 < 2 * NRI) issue_x(xb[(t + 1) & 1], c + tok, (t + 1) / NRI, nth_bit<ROWS>((t + 1) % NRI));
+        if (TAB && DBL && ri == NRI - 1) {
+          const int nc = half == 0 ? c : min(c + 1, nchunks - 1);
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const float4 x = xv[j];
-            inp[h] = (inp[h] + x.x * ph[4 * j]) + x.y * ph[4 * j + 1];        // cc:206
-            quad[h] = (quad[h] - x.x * ph[4 * j + 1]) + x.y * ph[4 * j];      // cc:207
-            inp[h] = (inp[h] + x.z * ph[4 * j + 2]) + x.w * ph[4 * j + 3];
-            quad[h] = (quad[h] - x.z * ph[4 * j + 3]) + x.w * ph[4 * j + 2];
-          }
-        } else {
-          const int hs = SHARED ? 0 : h;
+          for (int i = 0; i < NI; i++)
+            run[set ^ 1][i] = *(const K6_CONST f16v *)(tabw + tok + run_off(nc, half ^ 1, nth_bit<SM>(i)));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the arithmetic of row-item t
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const float4 x = xv[j];
+        for (int i = 0; i < NI; i++) {
+          const int h = nth_bit<SM>(i);
+          if (!((G::row_mask(SLOT, h) >> r) & 1u)) continue;   // compile time
+          const int k0 = 16 * c + 8 * half - 8 * G::dk8(h);    // uniform: this hypothesis' first step
+          const bool on = ((wmask >> h) & 1u) && k0 >= 0 && k0 <= 248;
+          if (on) {
+            if (TAB) {
+              const f16v &ph = run[set][i];
 #pragma unroll
-            for (int e = 0; e < 2; e++) {
-              const float xx = e ? x.z : x.x, xy = e ? x.w : x.y;
-              inp[h] = (inp[h] + xx * pc[h]) + xy * psn[h];                   // cc:206
-              quad[h] = (quad[h] - xx * psn[h]) + xy * pc[h];                 // cc:207
-              const float nc = pc[h] * cd[hs] - psn[h] * sd[hs];              // cc:193-195
-              const float ns = pc[h] * sd[hs] + psn[h] * cd[hs];
-              pc[h] = nc; psn[h] = ns;
+              for (int j = 0; j < 4; j++) {
+                inp[r][h] = (inp[r][h] + x[j].x * ph[4 * j]) + x[j].y * ph[4 * j + 1];        // cc:206
+                quad[r][h] = (quad[r][h] - x[j].x * ph[4 * j + 1]) + x[j].y * ph[4 * j];      // cc:207
+                inp[r][h] = (inp[r][h] + x[j].z * ph[4 * j + 2]) + x[j].w * ph[4 * j + 3];
+                quad[r][h] = (quad[r][h] - x[j].z * ph[4 * j + 3]) + x[j].w * ph[4 * j + 2];
+              }
+            } else {
+              const int hs = SHARED ? 0 : h;
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                  const float xx = e ? x[j].z : x[j].x, xy = e ? x[j].w : x[j].y;
+                  inp[r][h] = (inp[r][h] + xx * pc[r][h]) + xy * psn[r][h];             // cc:206
+                  quad[r][h] = (quad[r][h] - xx * psn[r][h]) + xy * pc[r][h];           // cc:207
+                  const float nc = pc[r][h] * cd[r][hs] - psn[r][h] * sd[r][hs];        // cc:193-195
+                  const float ns = pc[r][h] * sd[r][hs] + psn[r][h] * cd[r][hs];
+                  pc[r][h] = nc; psn[r][h] = ns;
+                }
+              }
             }
+          }
+          // four hypotheses per slot (S5): the run is reloaded in place for the next half as soon
+          // as its last row of this half is done
+          if (TAB && !DBL && ri == NRI - 1) {
+            const int nc = half == 0 ? c : min(c + 1, nchunks - 1);
+            run[0][i] = *(const K6_CONST f16v *)(tabw + run_off(nc, half ^ 1, h));
           }
         }
       }
+      gstore(c + 1, std::integral_constant<int, PAR ^ 1>{});
+      __syncthreads();
+    };
+    for (int c = 0; c < nchunks; c += 2) {   // nchunks is even
+      do_chunk(c, std::integral_constant<int, 0>{});
+      do_chunk(c + 1, std::integral_constant<int, 1>{});
     }
-    gstore((c + 1) & 1);
-    __syncthreads();
-  }
-  // tone magnitudes (cc:211) into the p image, which overlays the (now dead) staging buffers
-  if (has_row) {
+    // tone magnitudes (cc:211) into the p image, which overlays the (now dead) staging buffers
+    if (lane < K6_TROWS || virt) {
 #pragma unroll
-    for (int h = 0; h < HMAX; h++)
-      if ((mask >> h) & 1u)
-        stage[h * K6_PSLAB + row * 4 + tone] = ieee_sqrtf(inp[h] * inp[h] + quad[h] * quad[h]);
+      for (int r = 0; r < NR; r++) {
+        if (virt && r != 2) continue;
+        const int row = virt ? UWSPR_NSYM : row0 + K6_TROWS * r;
+#pragma unroll
+        for (int h = 0; h < HMAX; h++)
+          if (((SM >> h) & 1u) && ((G::row_mask(SLOT, h) >> r) & 1u) && ((wmask >> h) & 1u))
+            stage[h * K6_PSLAB + row * 4 + tone] = ieee_sqrtf(inp[r][h] * inp[r][h] + quad[r][h] * quad[r][h]);
+      }
+    }
+  };
+
+  gload(0, std::integral_constant<int, 0>{});
+  gstore(0, std::integral_constant<int, 0>{});
+  gload(1, std::integral_constant<int, 1>{});
+  __syncthreads();
+  // every slot executes the same number of barriers (one per chunk)
+  switch (wv >> 2) {
+    case 0: walk(std::integral_constant<int, 0>{}); break;
+    case 1: walk(std::integral_constant<int, 1>{}); break;
+    case 2: walk(std::integral_constant<int, 2>{}); break;
+    default: walk(std::integral_constant<int, 3>{}); break;
   }
   __syncthreads();
 }
 
-// ---- fold of one hypothesis by one wavefront (cc:213-226; SOFT: cc:216-224, 240-254) -----------
-// slab: [rows][4] tone magnitudes in LDS.  Returns sync in every lane.
+// ---- fold: cc:213-226 (sync) and, SOFT, cc:216-224 + 240-254 (soft symbols) + cc:469-474 (rms) -
+// NH hypotheses at a time; hypothesis j reads the [rows][4] magnitudes at slab[j] (LDS).
+struct k6_fold_lds {
+  float cm[K6_FOLDH][K6_CMS];          // signed cmet per symbol (cc:214-215); later symbol - 128 (cc:471)
+  double q[2][K6_FOLDH][UWSPR_NSYM];   // fs/162, fs*fs/162 (cc:243-244)
+  float sums[5][K6_FOLDH + 1];         // totp, ss, fsum, f2sum, sq per hypothesis
+};
+
 template <bool SOFT>
-__device__ __forceinline__ float k6_fold(const float *slab, k6_scr &S, float symfac, uint8_t *sym_out,
-                                         float *rms_out) {
-  const int lane = threadIdx.x & 63;
-  const float4 *s4 = reinterpret_cast<const float4 *>(slab);
-  float fsr[3];
-#pragma unroll
-  for (int r = 0; r < 3; r++) {
-    const int i = lane + 64 * r;
-    fsr[r] = 0.0f;
-    if (i < UWSPR_NSYM) {
-      const float4 P = s4[i];
-      const bool bit = pr3_6(i);
-      const float cmet = (P.y + P.w) - (P.x + P.z);   // cc:214
-      S.cm[i] = bit ? cmet : -cmet;                   // ss -/+ cmet == ss + (-/+ cmet)
-      fsr[r] = bit ? P.w - P.y : P.z - P.x;           // cc:219,222
-      if (SOFT) {
-        S.q[0][i] = (double)fsr[r] / 162.0;                  // cc:243
-        S.q[1][i] = (double)(fsr[r] * fsr[r]) / 162.0;       // cc:244
+__device__ __noinline__ void k6_fold(int nh, const int *slab_off, const lds_f *lds0, K6_LDS k6_fold_lds *Fp,
+                                     float *sync_out, uint8_t *sym0, float *rms_out) {
+  // slab_off[j]: dword offset (from lds0) of hypothesis j's [rows][4] magnitudes; its soft symbols
+  // go to sym0 + 162 j; sync_out / rms_out: generic pointers (LDS sy[] or the output record)
+  K6_LDS k6_fold_lds &F = *Fp;
+  nh = uni(nh);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = uni(tid >> 6);
+  // per-symbol terms, all threads
+  for (int e = tid; e < nh * UWSPR_NSYM; e += K6_THREADS) {
+    const int j = e / UWSPR_NSYM, i = e - j * UWSPR_NSYM;
+    const v4f P = ((const lds_f4 *)(lds0 + slab_off[j]))[i];
+    const bool bit = pr3_6(i);
+    const float cmet = (P.y + P.w) - (P.x + P.z);   // cc:214
+    F.cm[j][i] = bit ? cmet : -cmet;                // ss -/+ cmet == ss + (-/+ cmet)
+    if (SOFT) {
+      const float fs = bit ? P.w - P.y : P.z - P.x;          // cc:219,222
+      F.q[0][j][i] = (double)fs / 162.0;                     // cc:243
+      F.q[1][j][i] = (double)(fs * fs) / 162.0;              // cc:244
+    }
+  }
+  __syncthreads();
+  // the order-sensitive sums: one hypothesis per lane, one kind of sum per wavefront
+  if (lane < nh) {
+    if (wv == 0) {
+      const lds_f4 *s4 = (const lds_f4 *)(lds0 + slab_off[lane]);
+      float acc = 0.0f;
+#pragma unroll 9
+      for (int i = 0; i < UWSPR_NSYM; i++) {            // cc:213
+        const v4f P = s4[i];
+        acc = acc + P.x; acc = acc + P.y; acc = acc + P.z; acc = acc + P.w;
       }
+      F.sums[0][lane] = acc;
+    } else if (wv == 1) {
+      float acc = 0.0f;
+#pragma unroll 9
+      for (int i = 0; i < UWSPR_NSYM; i++) acc = acc + F.cm[lane][i];   // cc:215
+      F.sums[1][lane] = acc;
+    } else if (SOFT && (wv == 2 || wv == 3)) {
+      const K6_LDS double *q = F.q[wv - 2][lane];
+      float acc = 0.0f;
+#pragma unroll 9
+      for (int i = 0; i < UWSPR_NSYM; i++) acc = (float)((double)acc + q[i]);
+      F.sums[wv][lane] = acc;
     }
   }
-  k6_wave_fence();
-  float acc = 0.0f;
-  if (lane == 0) {
-#pragma unroll 9
-    for (int i = 0; i < UWSPR_NSYM; i++) {            // cc:213
-      const float4 P = s4[i];
-      acc = acc + P.x; acc = acc + P.y; acc = acc + P.z; acc = acc + P.w;
-    }
-  } else if (lane == 1) {
-#pragma unroll 9
-    for (int i = 0; i < UWSPR_NSYM; i++) acc = acc + S.cm[i];   // cc:215
-  } else if (SOFT && lane < 4) {
-    const double *q = S.q[lane - 2];
-#pragma unroll 9
-    for (int i = 0; i < UWSPR_NSYM; i++) acc = (float)((double)acc + q[i]);
-  }
-  const float totp = __shfl(acc, 0), ss = __shfl(acc, 1);
-  const float sync = ieee_divf(ss, totp);   // cc:226
+  __syncthreads();
+  if (tid < nh) sync_out[tid] = ieee_divf(F.sums[1][tid], F.sums[0][tid]);   // cc:226
   if (SOFT) {
-    const float fsum = __shfl(acc, 2), f2sum = __shfl(acc, 3);
-    const float fac = ieee_sqrtf(f2sum - fsum * fsum);   // cc:246
-    k6_wave_fence();   // cm[] is read no more
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const int i = lane + 64 * r;
-      if (i < UWSPR_NSYM) {
-        float v = ieee_divf(symfac * fsr[r], fac);   // cc:248
-        if (v > 127.0f) v = 127.0f;
-        if (v < -128.0f) v = -128.0f;
-        v = v + 128.0f;
-        const uint8_t b = (v != v) ? (uint8_t)0 : (uint8_t)(int)v;   // cc:251 (NaN -> 0)
-        sym_out[i] = b;
-        S.cm[i] = (float)((double)(float)b - 128.0);                 // cc:471
-      }
+    for (int e = tid; e < nh * UWSPR_NSYM; e += K6_THREADS) {
+      const int j = e / UWSPR_NSYM, i = e - j * UWSPR_NSYM;
+      const v4f P = ((const lds_f4 *)(lds0 + slab_off[j]))[i];
+      const float fs = pr3_6(i) ? P.w - P.y : P.z - P.x;
+      const float fsum = F.sums[2][j], f2sum = F.sums[3][j];
+      const float fac = ieee_sqrtf(f2sum - fsum * fsum);   // cc:246
+      float v = ieee_divf(50.0f * fs, fac);                // cc:248 (symfac = 50)
+      if (v > 127.0f) v = 127.0f;
+      if (v < -128.0f) v = -128.0f;
+      v = v + 128.0f;
+      const uint8_t b = (v != v) ? (uint8_t)0 : (uint8_t)(int)v;   // cc:251 (NaN -> 0)
+      sym0[j * UWSPR_NSYM + i] = b;
+      F.cm[j][i] = (float)((double)(float)b - 128.0);              // cc:471
     }
-    k6_wave_fence();
-    if (lane == 0) {
+    __syncthreads();
+    if (wv == 0 && lane < nh) {
       float sq = 0.0f;
 #pragma unroll 9
-      for (int i = 0; i < UWSPR_NSYM; i++) { const float y = S.cm[i]; sq += y * y; }   // cc:472
-      *rms_out = (float)sqrt((double)sq / 162.0);                                     // cc:474
+      for (int i = 0; i < UWSPR_NSYM; i++) { const float y = F.cm[lane][i]; sq += y * y; }   // cc:472
+      rms_out[lane] = (float)sqrt((double)sq / 162.0);                                      // cc:474
     }
   }
-  k6_wave_fence();
-  return sync;
+  __syncthreads();
 }
 
 // ---- table set: 5 frequencies x 4 tones x 256 steps of (c, s), cc:186-199 ----------------------
@@ -361,16 +526,13 @@ __device__ __forceinline__ const float *launder(const float *p) {
 __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
   __shared__ __align__(16) float stage[2 * K6_MAXROWS * K6_ROWDW];   // staging, then p[h][163][4]
   __shared__ __align__(16) float pw[UWSPR_NSYM * 4];                 // the current winner's magnitudes
-  __shared__ k6_scr scr[K6_FOLDW];
+  __shared__ k6_fold_lds F;
   __shared__ cand_state st;
-  __shared__ float sy[UWSPR_NJIG];
+  __shared__ float sy[UWSPR_NJIG + 1];
+  __shared__ int slab[K6_FOLDH];     // dword offsets from stage[] of the magnitudes being folded
   __shared__ int s_slot, s_wsrc, s_wroff, s_tq;
-  extern __shared__ char k6_pad[];   // launch-time padding: bounds the workgroups per CU
-  (void)k6_pad;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wv = uni(tid >> 6);
   float *tabA = a.tabs + (size_t)blockIdx.x * 2 * K6_TABSET;
   float *tabB = tabA + K6_TABSET;
   const bool reuse = a.reuse != 0;
@@ -393,7 +555,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
         s0.m_type = cnd.m_type;
         s0.slmc = (cnd.m_type == UWSPR_NONLINEAR)
                       ? k6_slm_drift_t0(cnd.m_nonlinear.V1, cnd.m_nonlinear.V2, cnd.m_nonlinear.p1,
-                                     cnd.m_nonlinear.p2, a.cf)
+                                        cnd.m_nonlinear.p2, a.cf)
                       : 0.0f;
         s0.f1 = cnd.freq;
         s0.drift1 = (cnd.m_type == UWSPR_LINEAR) ? cnd.m_linear.drift : 0.0f;   // cc:405,373
@@ -415,22 +577,23 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
       if (tid == 0 && a.state) a.state[slot] = st;
       continue;
     }
+    auto stamp = [&](int k) {
+      if (a.stamps && tid == 0) a.stamps[(size_t)slot * 64 + k] = wall_clock64();
+    };
+    stamp(0);
     const float2 *fb = a.frames + (size_t)st.frame * a.fl;
     const int m_type = uni(st.m_type);
     const float slmc = st.slmc;
 
-    // the fold + winner bookkeeping shared by the stages
+    // mode 0/1 fold of a 5- (2-) hypothesis stage: hypotheses of `mask` from the p image;
+    // `wrap_h` (S0): hypothesis 4 = hypothesis 0 one row later; the others are the known
+    // hypothesis (the previous winner: metric carried in st.csync)
     auto fold_plain = [&](int nh, uint32_t mask, int wrap_h) {
-      // hypotheses of `mask` from the p image; `wrap_h` (S0): hypothesis 4 = hypothesis 0 one row later
-      if (wv < K6_FOLDW) {
-        for (int h = wv; h < nh; h += K6_FOLDW) {
-          float s;
-          if ((mask >> h) & 1u) s = k6_fold<false>(&stage[h * K6_PSLAB], scr[wv], 50.0f, nullptr, nullptr);
-          else if (h == wrap_h) s = k6_fold<false>(&stage[4], scr[wv], 50.0f, nullptr, nullptr);
-          else s = st.csync;   // the known hypothesis: the previous winner, metric carried
-          if (lane == 0) sy[h] = s;
-        }
-      }
+      if (tid < nh)
+        slab[tid] = ((mask >> tid) & 1u) ? tid * K6_PSLAB : (tid == wrap_h ? 4 : (int)(pw - stage));
+      __syncthreads();
+      k6_fold<false>(nh, slab, (const lds_f *)stage, (K6_LDS k6_fold_lds *)&F, sy, nullptr, nullptr);
+      if (tid < nh && !((mask >> tid) & 1u) && tid != wrap_h) sy[tid] = st.csync;
       __syncthreads();
     };
     auto keep_winner = [&]() {
@@ -444,16 +607,17 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
     // =========================== S0 (cc:409-415): lag = shift1-128..+128 step 64, mode 0
     bool tabled = (m_type != UWSPR_LINEAR) || (st.drift1 == 0.0f);
     if (tabled) k6_build_tables(tabA, st.f1, 0.25f, m_type, st.drift1, slmc);
+    stamp(1);
     {
       const float f0v = st.f1 + (float)0 * 0.0f;
       const int L0 = st.shift1 - 128;
       if (tabled) {
         k6_pass<K6_S0, true>(fb, a.fl, L0, K6_MAXROWS, 28, 0x0fu, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc,
-                             launder(tabA), stage);
+                             launder(tabA), (lds_f *)stage);
         fold_plain(5, 0x0fu, 4);
       } else {
         k6_pass<K6_S0, false>(fb, a.fl, L0, UWSPR_NSYM, 32, 0x1fu, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc,
-                              tabA, stage);
+                              tabA, (lds_f *)stage);
         fold_plain(5, 0x1fu, -1);
       }
       if (tid == 0) {   // transition to S1 (sched_step_body<1>)
@@ -469,6 +633,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
       keep_winner();
     }
 
+    stamp(2);
     // =========================== S1 (cc:416-419): f = f1 + ifreq 0.25, mode 1
     {
       const float fc = st.f1;
@@ -480,9 +645,12 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
 #pragma unroll
       for (int q = 0; q < 5; q++) f0[q] = fc + (float)(q - 2) * 0.25f;
       const int L0 = st.shift1;
-      if (tabs_ok) k6_pass<K6_S1, true>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.25f, st.drift1, 0.0f, m_type, slmc, launder(tabA), stage);
-      else k6_pass<K6_S1, false>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.25f, st.drift1, 0.0f, m_type, slmc, tabA, stage);
+      if (tabs_ok) k6_pass<K6_S1, true>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.25f, st.drift1, 0.0f, m_type, slmc, launder(tabA), (lds_f *)stage,
+                                        a.stamps ? a.stamps + (size_t)slot * 64 + 16 : nullptr);
+      else k6_pass<K6_S1, false>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.25f, st.drift1, 0.0f, m_type, slmc, tabA, (lds_f *)stage);
+      stamp(10);
       fold_plain(5, mask, -1);
+      stamp(11);
       if (tid == 0) {   // transition to S2 (sched_step_body<2>)
         float bs = -1e30f; int bshift = 0; float bf = 0.0f; int bq = -1;
         for (int q = 0; q < 5; q++)
@@ -499,10 +667,11 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
       keep_winner();
     }
 
+    stamp(3);
     // =========================== S2 (cc:423-441): linear only, drift1 +- 0.5 at (f1, shift1)
     if (m_type == UWSPR_LINEAR) {
       const float f0v = st.f1 + (float)0 * 0.0f;
-      k6_pass<K6_S2, false>(fb, a.fl, st.shift1, UWSPR_NSYM, 16, 0x3u, 0, f0v, 0.0f, st.driftp, st.driftm, m_type, slmc, tabA, stage);
+      k6_pass<K6_S2, false>(fb, a.fl, st.shift1, UWSPR_NSYM, 16, 0x3u, 0, f0v, 0.0f, st.driftp, st.driftm, m_type, slmc, tabA, (lds_f *)stage);
       fold_plain(2, 0x3u, -1);
       if (tid == 0) {   // sched_step_body<3>, first half (cc:434-441)
         float syncp = -1e30f, syncm = -1e30f;
@@ -521,17 +690,19 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
     }
     __syncthreads();
 
+    stamp(4);
     const int njig = a.njig;
     if (st.worth) {
       // =========================== S3 (cc:444-447): lag = shift1-32..+32 step 16, mode 0
       tabled = (m_type != UWSPR_LINEAR) || (st.drift1 == 0.0f);
       if (tabled) k6_build_tables(tabB, st.f1, 0.05f, m_type, st.drift1, slmc);
+      stamp(5);
       {
         const float f0v = st.f1 + (float)0 * 0.0f;
         const int L0 = st.shift1 - 32;
         const uint32_t mask = st.cknown ? 0x1bu : 0x1fu;
-        if (tabled) k6_pass<K6_S3, true>(fb, a.fl, L0, UWSPR_NSYM, 20, mask, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc, launder(tabB), stage);
-        else k6_pass<K6_S3, false>(fb, a.fl, L0, UWSPR_NSYM, 20, mask, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc, tabB, stage);
+        if (tabled) k6_pass<K6_S3, true>(fb, a.fl, L0, UWSPR_NSYM, 20, mask, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc, launder(tabB), (lds_f *)stage);
+        else k6_pass<K6_S3, false>(fb, a.fl, L0, UWSPR_NSYM, 20, mask, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc, tabB, (lds_f *)stage);
         fold_plain(5, mask, -1);
         if (tid == 0) {   // sched_step_body<4>
           float bs = -1e30f; int bshift = 0; float bf = 0.0f; int bq = -1;
@@ -546,6 +717,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
         __syncthreads();
         keep_winner();
       }
+      stamp(6);
       // =========================== S4 (cc:449-452): f = f1 + ifreq 0.05, mode 1
       {
         const float fc = st.f1;
@@ -555,8 +727,8 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
 #pragma unroll
         for (int q = 0; q < 5; q++) f0[q] = fc + (float)(q - 2) * 0.05f;
         const int L0 = st.shift1;
-        if (tabs_ok) k6_pass<K6_S4, true>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.05f, st.drift1, 0.0f, m_type, slmc, launder(tabB), stage);
-        else k6_pass<K6_S4, false>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.05f, st.drift1, 0.0f, m_type, slmc, tabB, stage);
+        if (tabs_ok) k6_pass<K6_S4, true>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.05f, st.drift1, 0.0f, m_type, slmc, launder(tabB), (lds_f *)stage);
+        else k6_pass<K6_S4, false>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.05f, st.drift1, 0.0f, m_type, slmc, tabB, (lds_f *)stage);
         fold_plain(5, mask, -1);
         if (tid == 0) {   // sched_step_body<5>
           float bs = -1e30f; int bshift = 0; float bf = 0.0f; int bq = -1;
@@ -572,31 +744,42 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
         __syncthreads();
         keep_winner();
       }
+      stamp(7);
       // =========================== S5 (cc:457-482): the jiggered shifts, mode 2
       {
-        // try idt has shift ii = 8 (+-)ceil(idt/2); lags ascend from L0 = shift1 - 64
+        // try idt has shift 8 ii(idt), ii = (+-)ceil(idt/2); lags ascend from L0 = shift1 - 64
         const int wq = uni(s_tq);
         const bool tab5 = tabled && wq >= 0;
-        uint32_t mask = njig >= UWSPR_NJIG ? 0x1ffffu : ((1u << njig) - 1u);
+        const uint32_t want = njig >= UWSPR_NJIG ? 0x1ffffu : ((1u << njig) - 1u);
+        uint32_t mask = want;
         if (st.cknown) mask &= ~1u;   // try 0 repeats the S4 winner: its magnitudes are in pw
         const int L0 = st.shift1 - 64;
         if (mask) {
-          if (tab5) k6_pass<K6_S5, true>(fb, a.fl, L0, UWSPR_NSYM, 24, mask, wq, st.f1, 0.0f, st.drift1, 0.0f, m_type, slmc, launder(tabB), stage);
-          else k6_pass<K6_S5, false>(fb, a.fl, L0, UWSPR_NSYM, 24, mask, 0, st.f1, 0.0f, st.drift1, 0.0f, m_type, slmc, tabB, stage);
+          if (tab5) k6_pass<K6_S5, true>(fb, a.fl, L0, UWSPR_NSYM, 24, mask, wq, st.f1, 0.0f, st.drift1, 0.0f, m_type, slmc, launder(tabB), (lds_f *)stage);
+          else k6_pass<K6_S5, false>(fb, a.fl, L0, UWSPR_NSYM, 24, mask, 0, st.f1, 0.0f, st.drift1, 0.0f, m_type, slmc, tabB, (lds_f *)stage);
         }
-        if (wv < K6_FOLDW) {
-          for (int idt = wv; idt < UWSPR_NJIG; idt += K6_FOLDW) {
-            if (idt < njig) {
-              const float *slab = ((mask >> idt) & 1u) ? &stage[idt * K6_PSLAB] : pw;
-              const float s = k6_fold<true>(slab, scr[wv], 50.0f, &o->symbols[idt][0], &o->jig_rms[idt]);
-              int ii = (idt + 1) / 2;                      // cc:459-462
-              if (idt % 2 == 1) ii = -ii;
-              if (lane == 0) { o->jig_sync[idt] = s; o->jig_shift[idt] = st.shift1 + 8 * ii; }
-            } else {
-              for (int i = lane; i < UWSPR_NSYM; i += 64) o->symbols[idt][i] = 0;
-              if (lane == 0) { o->jig_sync[idt] = 0.0f; o->jig_rms[idt] = 0.0f; o->jig_shift[idt] = 0; }
-            }
+        stamp(8);
+        for (int base = 0; base < UWSPR_NJIG; base += K6_FOLDH) {
+          const int nh = min(K6_FOLDH, UWSPR_NJIG - base);
+          const int nwant = max(0, min(nh, njig - base));   // the tries wanted are a prefix
+          if (tid < nh) {
+            const int idt = base + tid;
+            slab[tid] = ((mask >> idt) & 1u) ? idt * K6_PSLAB : (int)(pw - stage);
           }
+          __syncthreads();
+          if (nwant > 0)
+            k6_fold<true>(nwant, slab, (const lds_f *)stage, (K6_LDS k6_fold_lds *)&F, &o->jig_sync[base],
+                          &o->symbols[base][0], &o->jig_rms[base]);
+          if (tid < nh) {
+            const int idt = base + tid;
+            int ii = (idt + 1) / 2;                      // cc:459-462
+            if (idt % 2 == 1) ii = -ii;
+            if (tid < nwant) o->jig_shift[idt] = st.shift1 + 8 * ii;
+            else { o->jig_sync[idt] = 0.0f; o->jig_rms[idt] = 0.0f; o->jig_shift[idt] = 0; }
+          }
+          for (int e = tid; e < (nh - nwant) * UWSPR_NSYM; e += K6_THREADS)
+            (&o->symbols[base + nwant][0])[e] = 0;
+          __syncthreads();
         }
       }
     } else {
@@ -604,6 +787,8 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
       uint32_t *ow = reinterpret_cast<uint32_t *>(o);
       for (int e = tid + 5; e < (int)(sizeof(uwspr_demod_out) / 4); e += K6_THREADS) ow[e] = 0u;
     }
+    __syncthreads();
+    stamp(9);
     if (tid == 0) {
       o->f1 = st.f1; o->drift1 = st.drift1; o->sync1 = st.sync1; o->shift1 = st.shift1;
       o->worth_a_try = st.worth; o->_pad[0] = 0; o->_pad[1] = 0;
@@ -619,18 +804,17 @@ void launch_sched_fused(uwspr_ctx *c, const float *frames, int B, const uwspr_ca
                         int njig) {
   const int nslots = B * per_frame;
   if (nslots <= 0) return;
-  prof_scope ps(c, UWSPR_K_TONECORR, nslots, true);
+  prof_scope ps(c, UWSPR_K_TONECORR, (int64_t)nslots * 35, true);
   k6_args a;
   a.frames = (const float2 *)frames; a.fl = c->fc.fl; a.nframes = B;
   a.cands = cands; a.npk = npk; a.cand_stride = cand_stride; a.per_frame = per_frame; a.nslots = nslots;
   a.cf = (float)c->p.cf; a.reuse = c->reuse_centre ? 1 : 0;
   a.njig = njig;
   a.tabs = c->d_tabs; a.counter = c->d_counter; a.out = out; a.state = c->d_state; a.pwin = nullptr;
+  a.stamps = c->d_sched_stamps;
   const int grid = nslots < c->sched_grid ? nslots : c->sched_grid;
-  // with no more candidates than CUs, keep them one per CU (a CU has room for two of these workgroups)
-  const size_t pad = (nslots <= c->num_cus && !c->sched_nopad) ? 40 * 1024 : 0;
   (void)hipMemsetAsync(c->d_counter, 0, sizeof(int), c->stream);
-  launch_timed(c, ps, k6_sched, dim3(grid), dim3(K6_THREADS), pad, a);
+  launch_timed(c, ps, k6_sched, dim3(grid), dim3(K6_THREADS), 0, a);
 }
 
 }  // namespace uwspr

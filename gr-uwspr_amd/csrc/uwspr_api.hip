@@ -115,7 +115,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->use_stage_grid = getenv("UWSPR_K4_STAGE_GRID") && atoi(getenv("UWSPR_K4_STAGE_GRID")) != 0;
   c->cap_slab = 0; c->d_slab = nullptr;
   c->sched_grid = getenv("UWSPR_SCHED_GRID") ? atoi(getenv("UWSPR_SCHED_GRID")) : 0;
-  c->cap_tabs = 0; c->d_tabs = nullptr; c->d_counter = nullptr;
+  c->cap_tabs = 0; c->d_tabs = nullptr; c->d_counter = nullptr; c->d_sched_stamps = nullptr; c->cap_sched_stamps = 0;
   *out = c;  // handed back even on failure so uwspr_last_error() can be read
 
   fdr_consts &f = c->fc;
@@ -267,7 +267,7 @@ extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
   void *bufs[] = {c->d_window, c->d_twiddle, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
                   c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_cent,
-                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter};
+                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter, c->d_sched_stamps};
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (auto &e : c->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -644,9 +644,11 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
   if ((rc = ensure(c, &c->d_state, &c->cap_state, nslots))) return rc;
   if (c->use_fused) {
     // k6_sched: one workgroup per candidate, S0..S5 back to back
-    if (c->sched_grid <= 0) c->sched_grid = 2 * c->num_cus;
+    if (c->sched_grid <= 0) c->sched_grid = c->num_cus;   // one 16-wave workgroup per CU
     if ((rc = ensure(c, &c->d_tabs, &c->cap_tabs, (size_t)c->sched_grid * kSchedTabFloats))) return rc;
     if (!c->d_counter) HIPCHK(c, hipMalloc((void **)&c->d_counter, 64));
+    if (getenv("UWSPR_SCHED_STAMPS") && atoi(getenv("UWSPR_SCHED_STAMPS")) &&
+        (rc = ensure(c, &c->d_sched_stamps, &c->cap_sched_stamps, nslots * 64))) return rc;
     if ((rc = ensure(c, &c->d_dout, &c->cap_dout, nslots))) return rc;
     c->cur_dout = user_out ? user_out : c->d_dout;
     launch_sched_fused(c, dframes, B, dcands, dnpk, cand_stride, per_frame, c->cur_dout, UWSPR_NJIG);
@@ -771,6 +773,14 @@ extern "C" int uwspr_pack_slabs(uwspr_ctx *c, int B, int K, void *slabs, int whe
 }
 
 // -------------------------------------------------------------- profiling
+// diagnostics (not part of the ABI header): phase boundary times of the last fused schedule launch
+extern "C" int uwspr_debug_sched_stamps(uwspr_ctx *c, unsigned long long *out, int nslots) {
+  if (!c || !out || !c->d_sched_stamps || (size_t)nslots * 64 > c->cap_sched_stamps) return UWSPR_ERR_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, c->d_sched_stamps, (size_t)nslots * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return UWSPR_OK;
+}
+
 extern "C" int uwspr_prof_enable(uwspr_ctx *c, int mask) {
   int rc = ready(c);
   if (rc) return rc;

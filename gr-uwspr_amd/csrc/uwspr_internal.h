@@ -146,6 +146,7 @@ struct uwspr_ctx {
   bool use_fused; bool sched_nopad; int sched_grid;
   size_t cap_tabs; float *d_tabs;     // [sched_grid][2][5][4][256](c, s) phasor tables
   int *d_counter;                     // candidate queue head of the running launch
+  unsigned long long *d_sched_stamps; size_t cap_sched_stamps;   // UWSPR_SCHED_STAMPS=1: phase times of the last launch
   size_t cap_slab; uint8_t *d_slab;
 
   int prof_mask;

@@ -15,7 +15,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
-LIBPATH = os.path.join(LIBDIR, "libuwspr_hip.so")
+# Experiment builds (UWSPR_EXTRA_HIPFLAGS set: -DK6_EXP=..., stamps, flag A/Bs) go to their OWN
+# library file, so the product libuwspr_hip.so is never replaced by a build whose results may be
+# invalid; with the variable unset the product library is (re)built from the default flags.
+_EXTRA = os.environ.get("UWSPR_EXTRA_HIPFLAGS", "").split()
+LIBPATH = os.path.join(LIBDIR, "libuwspr_hip_exp.so" if _EXTRA else "libuwspr_hip.so")
 HOSTLIB = os.path.join(LIBDIR, "libuwspr_blocks.so")
 
 SOURCES = ["uwspr_api.hip", "k0_frontend.hip", "k1_spectrogram.hip", "k2_spectrum.hip", "k3_coarse.hip",
@@ -48,6 +52,18 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _digest(paths):
+    """Content hash of the build inputs: what decides whether the library is current (file
+    times do not survive a copy to another machine; contents do)."""
+    import hashlib
+    h = hashlib.sha256()
+    for q in sorted(paths):
+        h.update(os.path.basename(q).encode())
+        with open(q, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 every kernel + the C ABI into lib/libuwspr_hip.so,
     then the host block mirror (gr-uwspr_amd/host) into lib/libuwspr_blocks.so."""
@@ -55,21 +71,22 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     deps.append(os.path.join(_HERE, "..", "include", "uwspr_hip.h"))
-    extra = os.environ.get("UWSPR_EXTRA_HIPFLAGS", "").split()   # experiments only
+    extra = _EXTRA   # experiments only (separate output file, see LIBPATH)
     cmd = [_hipcc()] + HIPFLAGS + extra + ["-shared", "-pthread"] + srcs + ["-o", LIBPATH]
     stamp = LIBPATH + ".cmd"
-    same_cmd = os.path.exists(stamp) and open(stamp).read() == " ".join(cmd)
-    if force or not same_cmd or _stale(LIBPATH, deps):
+    want = " ".join(cmd) + "\n" + _digest(deps)
+    same = os.path.exists(LIBPATH) and os.path.exists(stamp) and open(stamp).read() == want
+    if force or not same:
         if verbose:
             print(" ".join(cmd))
         subprocess.run(cmd, check=True)
-        open(stamp, "w").write(" ".join(cmd))
+        open(stamp, "w").write(want)
     hostdir = os.path.join(_HERE, "host")
     hsrcs = [os.path.join(hostdir, f) for f in sorted(os.listdir(hostdir)) if f.endswith(".cc")] \
         if os.path.isdir(hostdir) else []
     if hsrcs:
         hdeps = hsrcs + [os.path.join(hostdir, f) for f in os.listdir(hostdir) if f.endswith(".h")]
-        if force or _stale(HOSTLIB, hdeps + [LIBPATH]):
+        if not extra and (force or _stale(HOSTLIB, hdeps + [LIBPATH])):
             cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + hostdir,
                    "-I" + os.path.join(_HERE, "..", "include")] + hsrcs + \
                   ["-o", HOSTLIB, "-L" + LIBDIR, "-luwspr_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
@@ -142,8 +159,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIBPATH):
+    # always through build(): the command stamp + mtime check is cheap and a stale or foreign
+    # library is never loaded silently.  Where the sources cannot be compiled (no hipcc on a
+    # deployment box) an existing library is used as it is.
+    try:
         build()
+    except (UwsprError, subprocess.CalledProcessError, OSError):
+        if not os.path.exists(LIBPATH):
+            raise
     # One HIP/HSA runtime per process: PyTorch bundles its own libamdhip64.so.7 /
     # libhsa-runtime64 and this library is linked against /opt/rocm's (same SONAME).
     # Whichever is loaded first serves both; two live copies leave the second one
