@@ -164,8 +164,7 @@ template <int KIND, bool TAB>
 __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int fl, int L0, int nrows,
                                      int nchunks, uint32_t mask, int tq0, float fc, float fstep,
                                      float drp, float drm, int m_type, float slmc,
-                                     const float *tabset, lds_f *stage, unsigned long long *cst = nullptr) {
-  // cst (diagnostics, S1 only): wall-clock ticks of wavefront 0 at the start of every chunk
+                                     const float *tabset, lds_f *stage) {
   using G = k6_geom<KIND>;
   constexpr int HMAX = G::HMAX;
   constexpr bool SHARED = G::LAGS;
@@ -184,15 +183,8 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int fl, int 
   const int lr = tid >> 4, lj = tid & 15;
   const int sbase = lr * K6_ROWDW + 2 * lj;
   const bool interior = (L0 > 0) && (L0 + 256 * (nrows - 1) + 16 * nchunks < fl);   // workgroup-uniform
-  // frame loads run TWO chunks ahead of the arithmetic (a load from the Infinity Cache / HBM takes
-  // longer than one chunk's arithmetic): two register sets, alternating by chunk parity
-  float2 gregs[2][3];
-  auto gload = [&](int c, auto par) {
-    float2 (&greg)[3] = gregs[decltype(par)::value];
-#if defined(K6_EXP) && (K6_EXP & 1)   // timing experiment: no global loads in the walk
-    for (int n = 0; n < 3; n++) greg[n] = make_float2(0.5f + (float)c, 0.25f);
-    if (c >= 0) return;
-#endif
+  float2 greg[3];
+  auto gload = [&](int c) {
     if (interior) {
 #pragma unroll
       for (int n = 0; n < 3; n++) {
@@ -211,12 +203,11 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int fl, int 
       }
     }
   };
-  auto gstore = [&](int buf, auto par) {   // chunk `buf`'s samples (loaded two chunks ago) into LDS buffer buf & 1
-    float2 (&greg)[3] = gregs[decltype(par)::value];
+  auto gstore = [&](int buf) {
 #pragma unroll
     for (int n = 0; n < 3; n++)
       if (lr + 64 * n < nrows)
-        *(lds_f2 *)(&stage[(buf & 1) * K6_MAXROWS * K6_ROWDW + sbase + 64 * n * K6_ROWDW]) = v2f{greg[n].x, greg[n].y};
+        *(lds_f2 *)(&stage[buf * K6_MAXROWS * K6_ROWDW + sbase + 64 * n * K6_ROWDW]) = v2f{greg[n].x, greg[n].y};
   };
 
   // ---- the walk of one hypothesis slot: three rows per lane, the hypotheses of slot_mask(SLOT)
@@ -268,90 +259,53 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int fl, int 
     // rows this slot reads at all (S2's third slot walks only the last row of each lane)
     constexpr uint32_t ROWS = KIND == K6_S2 ? (SLOT == 2 ? 0x4u : SLOT == 3 ? 0u : 0x3u) : 0x7u;
 
-    // ---- the chunk loop, software-pipelined by hand.
-    // All sixteen wavefronts leave every barrier together and would run in lockstep -- read
-    // samples, wait, multiply, read, wait, ... -- so that LDS / scalar-memory time and VALU time
-    // ADD instead of overlapping (tools/mix_probe.hip: 0.32 instructions per cycle and SIMD
-    // against 0.5).  Hence: the unit of work is a ROW-ITEM (one of the lane's rows, 8 steps, all
-    // hypotheses of the slot: 64 multiply-adds each); the samples of row-item t+1 are requested
-    // right after the wait that opens row-item t, and the phasor runs of the next half during
-    // the last row-item of this half, so everything a wait drains was issued a row-item earlier.
-    // (SMEM returns out of order: with a scalar load pending every wait is "all outstanding" --
-    // so waits come first, requests second, arithmetic third, by explicit ordering.)
-    constexpr int NI = __builtin_popcount(SM & ((1u << HMAX) - 1u));    // hypotheses of this slot
-    constexpr int NRI = __builtin_popcount(ROWS);                        // rows per half
-    constexpr bool DBL = NI <= 2;     // phasor runs double-buffered by half (else reloaded in place)
-    constexpr int NSET = DBL ? 2 : 1;
-    auto run_off = [&](int cc, int hf, int h) {   // dword offset (from tabw) of hypothesis h's run at (chunk, half)
-      const int k0 = 16 * cc + 8 * hf - 8 * G::dk8(h);
-      return uni((SHARED ? 0 : h * 2048) + 2 * min(max(k0, 0), 248));
-    };
-    f16v run[NSET][NI > 0 ? NI : 1];
-    if (TAB) {
-#pragma unroll
-      for (int i = 0; i < NI; i++) run[0][i] = *(const K6_CONST f16v *)(tabw + run_off(0, 0, nth_bit<SM>(i)));
-    }
-    v4f xb[2][4];
-    auto issue_x = [&](v4f (&x)[4], int c, int half, int r) {
+    for (int c = 0; c < nchunks; c++) {
+      gload(min(c + 1, nchunks - 1));           // in flight during the arithmetic
+      const lds_f *rowp = &stage[(c & 1) * K6_MAXROWS * K6_ROWDW + (virt ? 0 : row0) * K6_ROWDW];
       // lane 54 (virtual row): its third row is row 162 = 108 + 54
-      const lds_f *rp = &stage[(c & 1) * K6_MAXROWS * K6_ROWDW + ((virt ? K6_TROWS : row0) + r * K6_TROWS) * K6_ROWDW + 16 * half];
+      for (int half = 0; half < 2; half++) {   // a real loop: halves the code
+        v4f xv[NR][4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) x[j] = *(const lds_f4 *)(rp + 4 * j);
-    };
-
-    auto do_chunk = [&](int c, auto par) {   // par = c & 1 (the chunk loop is unrolled by two: static register sets)
-      constexpr int PAR = decltype(par)::value;
-      if (KIND == K6_S1 && cst && tid == 0) cst[c] = wall_clock64();
-      gload(min(c + 2, nchunks - 1), par);   // chunk c + 2 has the parity of chunk c; lands two chunks later
-      if (NRI > 0) issue_x(xb[0], c, 0, nth_bit<ROWS>(0));
+        for (int r = 0; r < NR; r++) {
+          if (!((ROWS >> r) & 1u)) continue;
 #pragma unroll
-      for (int t = 0; t < 2 * NRI; t++) {
-        const int half = t / NRI, ri = t % NRI, r = nth_bit<ROWS>(ri);
-        const int set = DBL ? half : 0;
-        v4f (&x)[4] = xb[t & 1];
-        // ---- everything outstanding has landed: this row-item's samples, this half's runs
-        int tok = 0;
-        if (TAB && NI == 4)
-          asm volatile("; row-item ready" : "+s"(tok) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]),
-                       "s"(run[set][0]), "s"(run[set][NI > 1 ? 1 : 0]), "s"(run[set][NI > 2 ? 2 : 0]), "s"(run[set][NI > 3 ? 3 : 0]));
-        else if (TAB)
-          asm volatile("; row-item ready" : "+s"(tok) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]),
-                       "s"(run[set][0]), "s"(run[set][NI > 1 ? 1 : 0]));
-        else
-          asm volatile("; row-item ready" : "+s"(tok) : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
-        // ---- requests for the next row-item (tok ties them behind the wait)
-        if (t + 1 < 2 * NRI) issue_x(xb[(t + 1) & 1], c + tok, (t + 1) / NRI, nth_bit<ROWS>((t + 1) % NRI));
-        if (TAB && DBL && ri == NRI - 1) {
-          const int nc = half == 0 ? c : min(c + 1, nchunks - 1);
-#pragma unroll
-          for (int i = 0; i < NI; i++)
-            run[set ^ 1][i] = *(const K6_CONST f16v *)(tabw + tok + run_off(nc, half ^ 1, nth_bit<SM>(i)));
+          for (int j = 0; j < 4; j++)
+            xv[r][j] = *(const lds_f4 *)(rowp + (r * K6_TROWS + (virt ? K6_TROWS : 0)) * K6_ROWDW + 16 * half + 4 * j);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- the arithmetic of row-item t
 #pragma unroll
-        for (int i = 0; i < NI; i++) {
-          const int h = nth_bit<SM>(i);
-          if (!((G::row_mask(SLOT, h) >> r) & 1u)) continue;   // compile time
-          const int k0 = 16 * c + 8 * half - 8 * G::dk8(h);    // uniform: this hypothesis' first step
-          const bool on = ((wmask >> h) & 1u) && k0 >= 0 && k0 <= 248;
-          if (on) {
-            if (TAB) {
-              const f16v &ph = run[set][i];
+        for (int h = 0; h < HMAX; h++) {
+          if (!((SM >> h) & 1u)) continue;                   // compile time: not this slot's
+          if (!((wmask >> h) & 1u)) continue;                // uniform
+          const int k0 = 16 * c + 8 * half - 8 * G::dk8(h);  // uniform: this hypothesis' first step
+          if (k0 < 0 || k0 > 248) continue;
+          if (TAB) {
+            // 8 steps of (c, s) by one scalar load, used for three rows.  (The scalar path moves
+            // ~4 GB/s per CU when it streams -- tools/smem_probe.hip -- so every run is fetched
+            // by exactly one wavefront.)
+            const f16v ph = *(const K6_CONST f16v *)(tabw + (SHARED ? 0 : h * 2048) + 2 * k0);
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+              if (!((G::row_mask(SLOT, h) >> r) & 1u)) continue;
 #pragma unroll
               for (int j = 0; j < 4; j++) {
-                inp[r][h] = (inp[r][h] + x[j].x * ph[4 * j]) + x[j].y * ph[4 * j + 1];        // cc:206
-                quad[r][h] = (quad[r][h] - x[j].x * ph[4 * j + 1]) + x[j].y * ph[4 * j];      // cc:207
-                inp[r][h] = (inp[r][h] + x[j].z * ph[4 * j + 2]) + x[j].w * ph[4 * j + 3];
-                quad[r][h] = (quad[r][h] - x[j].z * ph[4 * j + 3]) + x[j].w * ph[4 * j + 2];
+                const v4f x = xv[r][j];
+                inp[r][h] = (inp[r][h] + x.x * ph[4 * j]) + x.y * ph[4 * j + 1];        // cc:206
+                quad[r][h] = (quad[r][h] - x.x * ph[4 * j + 1]) + x.y * ph[4 * j];      // cc:207
+                inp[r][h] = (inp[r][h] + x.z * ph[4 * j + 2]) + x.w * ph[4 * j + 3];
+                quad[r][h] = (quad[r][h] - x.z * ph[4 * j + 3]) + x.w * ph[4 * j + 2];
               }
-            } else {
-              const int hs = SHARED ? 0 : h;
+            }
+          } else {
+            const int hs = SHARED ? 0 : h;
+#pragma unroll
+            for (int r = 0; r < NR; r++) {
+              if (!((G::row_mask(SLOT, h) >> r) & 1u)) continue;
 #pragma unroll
               for (int j = 0; j < 4; j++) {
+                const v4f x = xv[r][j];
 #pragma unroll
                 for (int e = 0; e < 2; e++) {
-                  const float xx = e ? x[j].z : x[j].x, xy = e ? x[j].w : x[j].y;
+                  const float xx = e ? x.z : x.x, xy = e ? x.w : x.y;
                   inp[r][h] = (inp[r][h] + xx * pc[r][h]) + xy * psn[r][h];             // cc:206
                   quad[r][h] = (quad[r][h] - xx * psn[r][h]) + xy * pc[r][h];           // cc:207
                   const float nc = pc[r][h] * cd[r][hs] - psn[r][h] * sd[r][hs];        // cc:193-195
@@ -361,20 +315,10 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int fl, int 
               }
             }
           }
-          // four hypotheses per slot (S5): the run is reloaded in place for the next half as soon
-          // as its last row of this half is done
-          if (TAB && !DBL && ri == NRI - 1) {
-            const int nc = half == 0 ? c : min(c + 1, nchunks - 1);
-            run[0][i] = *(const K6_CONST f16v *)(tabw + run_off(nc, half ^ 1, h));
-          }
         }
       }
-      gstore(c + 1, std::integral_constant<int, PAR ^ 1>{});
+      gstore((c + 1) & 1);
       __syncthreads();
-    };
-    for (int c = 0; c < nchunks; c += 2) {   // nchunks is even
-      do_chunk(c, std::integral_constant<int, 0>{});
-      do_chunk(c + 1, std::integral_constant<int, 1>{});
     }
     // tone magnitudes (cc:211) into the p image, which overlays the (now dead) staging buffers
     if (lane < K6_TROWS || virt) {
@@ -390,9 +334,8 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int fl, int 
     }
   };
 
-  gload(0, std::integral_constant<int, 0>{});
-  gstore(0, std::integral_constant<int, 0>{});
-  gload(1, std::integral_constant<int, 1>{});
+  gload(0);
+  gstore(0);
   __syncthreads();
   // every slot executes the same number of barriers (one per chunk)
   switch (wv >> 2) {
@@ -645,8 +588,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
 #pragma unroll
       for (int q = 0; q < 5; q++) f0[q] = fc + (float)(q - 2) * 0.25f;
       const int L0 = st.shift1;
-      if (tabs_ok) k6_pass<K6_S1, true>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.25f, st.drift1, 0.0f, m_type, slmc, launder(tabA), (lds_f *)stage,
-                                        a.stamps ? a.stamps + (size_t)slot * 64 + 16 : nullptr);
+      if (tabs_ok) k6_pass<K6_S1, true>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.25f, st.drift1, 0.0f, m_type, slmc, launder(tabA), (lds_f *)stage);
       else k6_pass<K6_S1, false>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.25f, st.drift1, 0.0f, m_type, slmc, tabA, (lds_f *)stage);
       stamp(10);
       fold_plain(5, mask, -1);

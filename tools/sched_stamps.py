@@ -31,10 +31,6 @@ for k, n in enumerate(names):
     print("%-12s %9.2f %9.2f" % (n, np.median(d[:, k]), d[:, k].max()))
 print("S1 pass     %9.2f   S1 fold %9.2f   S1 rest %9.2f" % (np.median(t[:, 10] - t[:, 2]) / 100.0,
       np.median(t[:, 11] - t[:, 10]) / 100.0, np.median(t[:, 3] - t[:, 11]) / 100.0))
-ch = t[:, 16:32]
-print("S1: pass start -> chunk 0 %.2f us; chunk durations (median): %s; last chunk start -> pass end %.2f" % (
-      np.median(ch[:, 0] - t[:, 2]) / 100.0, " ".join("%.2f" % (np.median(ch[:, k + 1] - ch[:, k]) / 100.0) for k in range(15)),
-      np.median(t[:, 10] - ch[:, 15]) / 100.0))
 tot = (t[:, 9] - t[:, 0]) / 100.0
 print("total        %9.2f %9.2f" % (np.median(tot), tot.max()))
 print("launch span  %9.2f us (first start to last end)" % ((t[:, 9].max() - t[:, 0].min()) / 100.0))
