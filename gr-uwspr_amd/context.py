@@ -229,6 +229,25 @@ class Context:
                                            C.c_void_p(out.ctypes.data)))
         return out
 
+    def set_tries(self, ntries):
+        """Mode-2 tries per candidate the schedule calls produce (17 = all; fewer = lazy)."""
+        self._chk(self.L.uwspr_set_tries(self.h, int(ntries)))
+
+    def demod_resume(self, frames, need, out, max_per_frame=1):
+        """Produce all 17 tries for the slots flagged in `need` (uint8 [B, max_per_frame]) of the
+        last schedule call.  Host form: returns the full record array; device form (torch
+        tensors for need / out): in place."""
+        p, B, where, keep = self._frames(frames)
+        if where == N.DEVICE:
+            self._chk(self.L.uwspr_demod_resume(self.h, p, B, where, C.c_void_p(need.data_ptr()),
+                                                max_per_frame, C.c_void_p(out.data_ptr())))
+            return out
+        need = np.ascontiguousarray(need, np.uint8).reshape(B, max_per_frame)
+        res = np.zeros((B, max_per_frame), N.DEMOD_DTYPE)
+        self._chk(self.L.uwspr_demod_resume(self.h, p, B, where, C.c_void_p(need.ctypes.data),
+                                            max_per_frame, C.c_void_p(res.ctypes.data)))
+        return res
+
     def pipeline_batch(self, frames, max_per_frame=1, fetch=True):
         """FDR + refinement schedule. -> (cands list, demod_out[B,max_per_frame]) or None."""
         p, B, where, keep = self._frames(frames)

@@ -114,7 +114,8 @@ struct k6_args {
   int *counter;                 // slot queue head
   uwspr_demod_out *out;
   cand_state *state;            // [nslots] final state (resume / diagnostics)
-  float *pwin;                  // [nslots][162][4] winner magnitudes (resume), or null
+  float *pwin;                  // [nslots][162][4] winner magnitudes, kept for uwspr_demod_resume, or null
+  const uint8_t *resume;        // resume pass: [nslots] nonzero = produce the remaining tries of that slot (state, pwin are inputs)
   unsigned long long *stamps;   // diagnostics: [nslots][64] wall-clock ticks at the phase boundaries, or null
 };
 
@@ -487,8 +488,13 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
     const int slot = uni(s_slot);
     if (slot >= a.nslots) return;
 
+    const bool resume = a.resume != nullptr;
+    if (resume && !a.resume[slot]) continue;   // this slot keeps what the first pass wrote
     // ---- candidate -> state (k_sched_init; cc:404-407) ----
-    if (tid == 0) {
+    if (resume) {
+      if (tid == 0) st = a.state[slot];
+      for (int e = tid; e < UWSPR_NSYM * 4; e += K6_THREADS) pw[e] = a.pwin[(size_t)slot * UWSPR_NSYM * 4 + e];
+    } else if (tid == 0) {
       const int b = slot / a.per_frame, j = slot - b * a.per_frame;
       cand_state s0;
       const bool on = j < a.npk[b] && j < a.cand_stride;
@@ -514,6 +520,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
     __syncthreads();
     uwspr_demod_out *o = a.out + slot;
     const bool live = st.frame >= 0 && st.frame < a.nframes;
+    if (resume && live && !st.worth) continue;   // nothing more to produce (cc:453-457)
     if (!live) {
       uint32_t *ow = reinterpret_cast<uint32_t *>(o);
       for (int e = tid; e < (int)(sizeof(uwspr_demod_out) / 4); e += K6_THREADS) ow[e] = 0u;
@@ -549,6 +556,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
 
     // =========================== S0 (cc:409-415): lag = shift1-128..+128 step 64, mode 0
     bool tabled = (m_type != UWSPR_LINEAR) || (st.drift1 == 0.0f);
+    if (!resume) {
     if (tabled) k6_build_tables(tabA, st.f1, 0.25f, m_type, st.drift1, slmc);
     stamp(1);
     {
@@ -630,6 +638,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
       st.worth = (st.sync1 > 0.10f) ? 1 : 0;   // cc:443
       st.csync = st.sync1;
     }
+    }   // !resume
     __syncthreads();
 
     stamp(4);
@@ -637,8 +646,11 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
     if (st.worth) {
       // =========================== S3 (cc:444-447): lag = shift1-32..+32 step 16, mode 0
       tabled = (m_type != UWSPR_LINEAR) || (st.drift1 == 0.0f);
+      // (resume: the table set is rebuilt around the FINAL f1, whose middle table is the S5 frequency)
       if (tabled) k6_build_tables(tabB, st.f1, 0.05f, m_type, st.drift1, slmc);
+      if (resume && tid == 0) s_tq = 2;
       stamp(5);
+      if (!resume) {
       {
         const float f0v = st.f1 + (float)0 * 0.0f;
         const int L0 = st.shift1 - 32;
@@ -686,13 +698,15 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
         __syncthreads();
         keep_winner();
       }
+      }   // !resume
+      __syncthreads();
       stamp(7);
       // =========================== S5 (cc:457-482): the jiggered shifts, mode 2
       {
         // try idt has shift 8 ii(idt), ii = (+-)ceil(idt/2); lags ascend from L0 = shift1 - 64
         const int wq = uni(s_tq);
         const bool tab5 = tabled && wq >= 0;
-        const uint32_t want = njig >= UWSPR_NJIG ? 0x1ffffu : ((1u << njig) - 1u);
+        const uint32_t want = (resume || njig >= UWSPR_NJIG) ? 0x1ffffu : ((1u << njig) - 1u);
         uint32_t mask = want;
         if (st.cknown) mask &= ~1u;   // try 0 repeats the S4 winner: its magnitudes are in pw
         const int L0 = st.shift1 - 64;
@@ -703,7 +717,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
         stamp(8);
         for (int base = 0; base < UWSPR_NJIG; base += K6_FOLDH) {
           const int nh = min(K6_FOLDH, UWSPR_NJIG - base);
-          const int nwant = max(0, min(nh, njig - base));   // the tries wanted are a prefix
+          const int nwant = resume ? nh : max(0, min(nh, njig - base));   // the tries wanted are a prefix
           if (tid < nh) {
             const int idt = base + tid;
             slab[tid] = ((mask >> idt) & 1u) ? idt * K6_PSLAB : (int)(pw - stage);
@@ -731,19 +745,19 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
     }
     __syncthreads();
     stamp(9);
-    if (tid == 0) {
+    if (tid == 0 && !resume) {
       o->f1 = st.f1; o->drift1 = st.drift1; o->sync1 = st.sync1; o->shift1 = st.shift1;
       o->worth_a_try = st.worth; o->_pad[0] = 0; o->_pad[1] = 0;
       if (a.state) a.state[slot] = st;
     }
-    if (a.pwin && st.worth)
+    if (a.pwin && st.worth && !resume)
       for (int e = tid; e < UWSPR_NSYM * 4; e += K6_THREADS) a.pwin[(size_t)slot * UWSPR_NSYM * 4 + e] = pw[e];
   }
 }
 
 void launch_sched_fused(uwspr_ctx *c, const float *frames, int B, const uwspr_candidate *cands,
                         const int32_t *npk, int cand_stride, int per_frame, uwspr_demod_out *out,
-                        int njig) {
+                        int njig, const uint8_t *resume) {
   const int nslots = B * per_frame;
   if (nslots <= 0) return;
   prof_scope ps(c, UWSPR_K_TONECORR, (int64_t)nslots * 35, true);
@@ -752,7 +766,7 @@ void launch_sched_fused(uwspr_ctx *c, const float *frames, int B, const uwspr_ca
   a.cands = cands; a.npk = npk; a.cand_stride = cand_stride; a.per_frame = per_frame; a.nslots = nslots;
   a.cf = (float)c->p.cf; a.reuse = c->reuse_centre ? 1 : 0;
   a.njig = njig;
-  a.tabs = c->d_tabs; a.counter = c->d_counter; a.out = out; a.state = c->d_state; a.pwin = nullptr;
+  a.tabs = c->d_tabs; a.counter = c->d_counter; a.out = out; a.state = c->d_state; a.pwin = c->d_pwin; a.resume = resume;
   a.stamps = c->d_sched_stamps;
   const int grid = nslots < c->sched_grid ? nslots : c->sched_grid;
   (void)hipMemsetAsync(c->d_counter, 0, sizeof(int), c->stream);

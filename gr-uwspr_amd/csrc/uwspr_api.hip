@@ -115,6 +115,8 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->use_stage_grid = getenv("UWSPR_K4_STAGE_GRID") && atoi(getenv("UWSPR_K4_STAGE_GRID")) != 0;
   c->cap_slab = 0; c->d_slab = nullptr;
   c->sched_grid = getenv("UWSPR_SCHED_GRID") ? atoi(getenv("UWSPR_SCHED_GRID")) : 0;
+  c->ntries = UWSPR_NJIG; c->cap_pwin = 0; c->d_pwin = nullptr; c->cap_need = 0; c->d_need = nullptr;
+  c->last_slots = 0; c->last_sched_B = 0; c->last_sched_per_frame = 0;
   c->cap_tabs = 0; c->d_tabs = nullptr; c->d_counter = nullptr; c->d_sched_stamps = nullptr; c->cap_sched_stamps = 0;
   *out = c;  // handed back even on failure so uwspr_last_error() can be read
 
@@ -267,7 +269,7 @@ extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
   void *bufs[] = {c->d_window, c->d_twiddle, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
                   c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_cent,
-                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter, c->d_sched_stamps};
+                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter, c->d_sched_stamps, c->d_pwin, c->d_need};
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (auto &e : c->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -642,6 +644,8 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
   const size_t nslots = (size_t)B * per_frame;
   int rc;
   if ((rc = ensure(c, &c->d_state, &c->cap_state, nslots))) return rc;
+  if (!c->use_fused && c->ntries < UWSPR_NJIG)
+    return fail(c, UWSPR_ERR_UNSUPPORTED, "lazy tries (uwspr_set_tries) need the fused schedule kernel (UWSPR_SCHED_FUSED=1)");
   if (c->use_fused) {
     // k6_sched: one workgroup per candidate, S0..S5 back to back
     if (c->sched_grid <= 0) c->sched_grid = c->num_cus;   // one 16-wave workgroup per CU
@@ -651,7 +655,12 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
         (rc = ensure(c, &c->d_sched_stamps, &c->cap_sched_stamps, nslots * 64))) return rc;
     if ((rc = ensure(c, &c->d_dout, &c->cap_dout, nslots))) return rc;
     c->cur_dout = user_out ? user_out : c->d_dout;
-    launch_sched_fused(c, dframes, B, dcands, dnpk, cand_stride, per_frame, c->cur_dout, UWSPR_NJIG);
+    if (c->ntries < UWSPR_NJIG) {   // lazy tries: keep what a later uwspr_demod_resume needs
+      if ((rc = ensure(c, &c->d_pwin, &c->cap_pwin, nslots * UWSPR_NSYM * 4))) return rc;
+    }
+    launch_sched_fused(c, dframes, B, dcands, dnpk, cand_stride, per_frame, c->cur_dout,
+                       c->ntries < UWSPR_NJIG ? c->ntries : UWSPR_NJIG);
+    c->last_slots = (int)nslots; c->last_sched_B = B; c->last_sched_per_frame = per_frame;
     HIPCHK(c, hipGetLastError());
     return UWSPR_OK;
   }
@@ -747,6 +756,43 @@ extern "C" int uwspr_pipeline_batch(uwspr_ctx *c, const float *frames, int B, in
   if (c->cur_dout == c->d_dout &&
       (rc = copy_out(c, out, c->d_dout, (size_t)B * max_per_frame * sizeof(uwspr_demod_out), where))) return rc;
   if (where == UWSPR_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_set_tries(uwspr_ctx *c, int ntries) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (ntries < 1 || ntries > UWSPR_NJIG) return fail(c, UWSPR_ERR_ARG, "ntries=%d (1..%d)", ntries, UWSPR_NJIG);
+  if (ntries < UWSPR_NJIG && !c->use_fused)
+    return fail(c, UWSPR_ERR_UNSUPPORTED, "lazy tries need the fused schedule kernel (UWSPR_SCHED_FUSED=1)");
+  c->ntries = ntries;
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_demod_resume(uwspr_ctx *c, const float *frames, int B, int where, const uint8_t *need,
+                                  int max_per_frame, uwspr_demod_out *out) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!need || !out || B <= 0 || max_per_frame <= 0) return fail(c, UWSPR_ERR_ARG, "need/out/B/max_per_frame");
+  if (!c->use_fused || !c->d_pwin || c->last_sched_B != B || c->last_sched_per_frame != max_per_frame)
+    return fail(c, UWSPR_ERR_ARG, "uwspr_demod_resume follows a schedule call of the same batch made with uwspr_set_tries(< %d)", UWSPR_NJIG);
+  const float *d;
+  if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
+  const size_t nslots = (size_t)B * max_per_frame;
+  const uint8_t *dneed = need;
+  uwspr_demod_out *dout = out;
+  if (where == UWSPR_HOST) {
+    if ((rc = ensure(c, &c->d_need, &c->cap_need, nslots))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_need, need, nslots, hipMemcpyHostToDevice, c->stream));
+    dneed = c->d_need;
+    dout = c->d_dout;   // the records of the first pass are still there
+  }
+  launch_sched_fused(c, d, B, nullptr, nullptr, 0, max_per_frame, dout, UWSPR_NJIG, dneed);
+  HIPCHK(c, hipGetLastError());
+  if (where == UWSPR_HOST) {
+    HIPCHK(c, hipMemcpyAsync(out, c->d_dout, nslots * sizeof(uwspr_demod_out), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
   return UWSPR_OK;
 }
 

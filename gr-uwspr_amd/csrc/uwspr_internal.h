@@ -146,6 +146,10 @@ struct uwspr_ctx {
   bool use_fused; bool sched_nopad; int sched_grid;
   size_t cap_tabs; float *d_tabs;     // [sched_grid][2][5][4][256](c, s) phasor tables
   int *d_counter;                     // candidate queue head of the running launch
+  int ntries;                         // mode-2 tries per candidate a schedule call produces (uwspr_set_tries)
+  size_t cap_pwin; float *d_pwin;     // [nslots][162][4] winner magnitudes kept for uwspr_demod_resume (ntries < 17)
+  size_t cap_need; uint8_t *d_need;   // staging of the resume mask
+  int last_slots, last_sched_B, last_sched_per_frame;
   unsigned long long *d_sched_stamps; size_t cap_sched_stamps;   // UWSPR_SCHED_STAMPS=1: phase times of the last launch
   size_t cap_slab; uint8_t *d_slab;
 
@@ -191,7 +195,7 @@ void launch_sched_finish(uwspr_ctx *c, int ncand);
 // the whole schedule in one launch (k6_sched.hip); njig = mode-2 tries to produce (17 = all)
 void launch_sched_fused(uwspr_ctx *c, const float *frames, int B, const uwspr_candidate *cands,
                         const int32_t *npk, int cand_stride, int per_frame, uwspr_demod_out *out,
-                        int njig);
+                        int njig, const uint8_t *resume = nullptr);
 constexpr int kSchedTabFloats = 2 * 5 * 4 * 512;   // per resident workgroup
 
 // profiling brackets

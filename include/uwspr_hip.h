@@ -233,6 +233,21 @@ int uwspr_demod_batch(uwspr_ctx *ctx, const float *frames, int B, int where,
                       const uwspr_candidate *cands, const int32_t *npk,
                       int cand_stride, int max_per_frame, uwspr_demod_out *out);
 
+/* Lazy jiggered shifts.  The reference stops at the first of its up to 17 mode-2 tries that
+ * decodes (sync_and_demodulate_impl.cc:457-490); by default this library produces all 17 soft-symbol
+ * vectors before the host sees any.  uwspr_set_tries(ctx, k), k < 17: the schedule calls that follow
+ * produce only tries idt < k (the other entries of uwspr_demod_out are zero, so uwspr_decode_candidate
+ * skips them) and keep what is needed to produce the rest later.  Try 0 repeats the hypothesis that won
+ * the last stage, so k = 1 costs no correlation at all.
+ * uwspr_demod_resume(ctx, frames, B, where, need, max_per_frame, out): for the slots b*max_per_frame+j
+ * with need[...] != 0 of the LAST schedule call (same frames, B, max_per_frame) all 17 tries are
+ * produced, byte-identical to what a k = 17 call gives; the other records are left alone.
+ * where == UWSPR_HOST: need is host memory and `out` receives all B*max_per_frame records;
+ * UWSPR_DEVICE: need and out are device memory, out being the buffer the first call wrote. */
+int uwspr_set_tries(uwspr_ctx *ctx, int ntries);
+int uwspr_demod_resume(uwspr_ctx *ctx, const float *frames, int B, int where, const uint8_t *need,
+                       int max_per_frame, uwspr_demod_out *out);
+
 /* FDR followed by the schedule with candidates kept in HBM in between (the
  * FDR -> sync_and_demodulate PDU hop of the flowgraph, examples/
  * WaveFilePlusNoiseDecode.grc).  Any output pointer may be NULL. */

@@ -585,3 +585,49 @@ def test_coarse_search_offset_table_in_lds_or_hbm(G, frames, monkeypatch):
                 assert x.tobytes()[24:28] == y.tobytes()[24:28]
             if j < 2:
                 assert ga[b, j].tobytes() == gb[b, j].tobytes()
+
+
+def test_lazy_tries_and_resume_equal_the_eager_schedule(G, frames, vec):
+    """uwspr_set_tries(k) + uwspr_demod_resume: the reference stops at its first decoding try
+    (cc:457-490).  Tries idt < k of the lazy pass are byte-identical to the eager ones, the
+    rest is zero; after the resume the flagged records equal the eager records byte for byte
+    and the unflagged ones are untouched.  Host and device pointer forms."""
+    import torch
+    cands = [vec["cands"][b, :int(vec["npk"][b])] for b in range(4)]
+    per = max(len(c) for c in cands)
+    c = G.Context()
+    try:
+        eager = c.demod_batch(frames, cands, max_per_frame=per)
+        for k in (1, 3):
+            c.set_tries(k)
+            lazy = c.demod_batch(frames, cands, max_per_frame=per)
+            for f in ("f1", "drift1", "sync1", "shift1", "worth_a_try"):
+                assert lazy[f].tobytes() == eager[f].tobytes()
+            assert lazy["symbols"][:, :, :k].tobytes() == eager["symbols"][:, :, :k].tobytes()
+            assert lazy["jig_sync"][:, :, :k].tobytes() == eager["jig_sync"][:, :, :k].tobytes()
+            assert lazy["jig_rms"][:, :, :k].tobytes() == eager["jig_rms"][:, :, :k].tobytes()
+            assert not lazy["symbols"][:, :, k:].any() and not lazy["jig_sync"][:, :, k:].any()
+            need = np.zeros((4, per), np.uint8)
+            need[1, :] = 1
+            need[3, 0] = 1
+            res = c.demod_resume(frames, need, None, max_per_frame=per)
+            for b in range(4):
+                for j in range(per):
+                    want = eager[b, j] if need[b, j] else lazy[b, j]
+                    assert res[b, j].tobytes() == want.tobytes(), (k, b, j)
+        # device pointers, through the whole pipeline
+        c.set_tries(1)
+        dev = torch.from_numpy(frames).cuda()
+        cd = torch.empty(4 * c.maxfreqs * 48, dtype=torch.uint8, device="cuda")
+        nd = torch.empty(4, dtype=torch.int32, device="cuda")
+        od = torch.empty(4 * G.native.DEMOD_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        c.pipeline_batch_into(dev, cd, nd, od, max_per_frame=1)
+        needd = torch.ones(4, dtype=torch.uint8, device="cuda")
+        c.demod_resume(dev, needd, od, max_per_frame=1)
+        c.synchronize()
+        got = np.frombuffer(od.cpu().numpy().tobytes(), G.native.DEMOD_DTYPE)
+        c.set_tries(17)
+        _, full = c.pipeline_batch(frames, max_per_frame=1)
+        assert got.tobytes() == full[:, 0].tobytes()
+    finally:
+        c.close()
