@@ -1,30 +1,52 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of the coarse (FDR) + fine (sync_and_demodulate) path.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--total-frames T] [--repeats R]
 
 One step = one pass of the whole hot path (K1 spectrogram, K2 spectrum/peaks,
 K3 coarse search + selection over ALL candidates, then the S0..S5 refinement
-schedule incl. the 17 soft-symbol vectors for the top candidate of every frame)
-over one batch of synthetic frames that is already resident in HBM, followed by
-the gather of the per-frame candidate slabs to rank 0.  Workload = BASELINE.json
-configs[1]: 256 synthetic 375 Hz / 45000-sample frames per GPU at -20 dB, flowgraph
-default FDR grid, single candidate per frame.  For N>1 every rank runs its own
-256 frames (weak scaling); frames shard with no data-path collective.
+schedule incl. the 17 soft-symbol vectors for the top candidate of every frame,
+and the packing of the per-frame candidate slabs) over one batch of synthetic
+frames that is already resident in HBM.  The slabs of all K steps go to rank 0 in
+ONE gather at the end of the timed region (inside it).
+
+Workload = BASELINE.json configs[1]: 256 synthetic 375 Hz / 45000-sample frames
+per GPU at -20 dB, flowgraph-default FDR grid, single candidate per frame.  The
+timed steps rotate over FIVE distinct batches (460 MB, more than the 256 MiB
+Infinity Cache), so every step ingests frames that are not cache-resident.
+  weak scaling (default)   every rank runs its own 256 frames per step;
+  --total-frames T         strong scaling (BASELINE configs[3]: T = 65536): the T frames
+                           of a step are sharded round-robin, T / N per rank.
+Frames shard with no data-path collective; the one exchange is the final gather.
+
+`--gpus N` run bare (no WORLD_SIZE in the environment) starts the N ranks itself, one
+process per GPU, BEFORE anything touches the GPU in the parent; on a box with fewer
+devices than ranks the ranks share the devices and talk gloo (a rehearsal, flagged
+in the JSON).  Under torch.distributed.run the environment's ranks are used.
+
+The timed region (K steps between barrier + synchronize) is repeated R times
+(default 5); `value` is the MEDIAN repeat, all repeats are listed.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      the dominant kernel (K4 tone correlation sweep): algorithmic
-                bytes/launch (331950 B per hypothesis) / HIP-event
-                time per launch, against the 8 TB/s HBM peak.
-  cpu_baseline  the CPU restatement (oracle/, kind "port") on a bounded sample
-                of the same workload on this box's host cores.
-  kernels       HIP-event time per kernel family per step.
-  sweep         (N=1) BASELINE configs[2]: 1024 frames x 200 (freq,lag,drift)
-                hypotheses through uwspr_sync_sweep, the north_star's roofline case.
+  roofline      the dominant kernel, the tone-correlation schedule (k6_sched, or the K4 family
+                of the staged form).  It is FP32-VALU bound (no FMA: the reference's
+                two-rounding sums), so `bound` = "valu_fp32_nofma": achieved = binary32
+                operations the launches' hypotheses need / kernel time, peak = 78.6 T op/s
+                (256 CU x 4 SIMD x 32 lanes x 2.4 GHz), frac = achieved / peak <= 1.
+                Secondary: the north-star "algorithmic bytes" rate (331950 B per hypothesis
+                as if every hypothesis streamed its windows from HBM) under its own names,
+                PMC-measured fabric traffic per launch, VALU issue utilisation from the
+                committed PMC pass.
+  cpu_baseline  the CPU restatement (oracle/, kind "port") on a bounded sample.
+  kernels       HIP-event time per kernel family per step (single stream).
+  lazy_s5       the same step with uwspr_set_tries(1): only the first jiggered shift.
+  sweep         (N=1) BASELINE configs[2]: 1024 frames x 200 (freq,lag,drift) hypotheses.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,9 +58,11 @@ for _p in (ROOT, os.path.join(ROOT, "oracle")):
         sys.path.insert(0, _p)
 
 HYP_BYTES = 162 * 256 * 8 + 162 + 12      # 331950 B per fine hypothesis
-HYP_FLOP = 162 * 4 * 256 * 14             # binary32 ops per hypothesis in K4
+OPS_MAC = 162 * 4 * 256 * 8               # binary32 ops of one hypothesis' correlation (cc:206-207)
+OPS_PHASOR = 162 * 4 * 256 * 6            # ... of its per-symbol phasor recurrences (cc:193-195)
 HBM_PEAK_GBS = 8000.0
 FP32_NOFMA_PEAK_TOPS = 78.6               # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one op/lane/clk
+NBATCH = 5                                # distinct batches the steps rotate over
 
 
 def cpu_baseline(frames_np, budget_s=12.0):
@@ -69,27 +93,63 @@ def cpu_baseline(frames_np, budget_s=12.0):
         list(ex.map(one, [(i % ncores, i % nb) for i in range(n)]))
     dt = time.time() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": ncores, "kind": "port",
-            "sample": "%d frame-passes over the benchmark's %d frames (oracle FDR over all candidates + "
+            "sample": "%d frame-passes over %d of the benchmark's frames (oracle FDR over all candidates + "
                       "S0..S5 schedule with 17 soft-symbol vectors for the top candidate), %d threads, "
                       "%.1f s wall = %.0f core-seconds" % (n, nb, ncores, dt, dt * ncores)}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--repeats", type=int, default=5, help="repeats of the timed K-step region")
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (weak scaling)")
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="strong scaling: frames per step over ALL ranks (configs[3]: 65536)")
     ap.add_argument("--snr", type=float, default=-20.0)
     ap.add_argument("--no-sweep", action="store_true")
-    ap.add_argument("--prof-steps", type=int, default=0,
-                    help="timed steps whose K4 launches are bracketed by HIP events (0 = all)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sweep-frames", type=int, default=1024)
-    ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams (each with its own context and scratch) the steps rotate over, "
-                         "so the tail of one batch overlaps the head of the next")
-    args = ap.parse_args()
+    ap.add_argument("--sched", choices=("auto", "fused", "staged"), default="auto",
+                    help="schedule form: k6_sched (one workgroup per candidate), the staged K4/K5 launches, "
+                         "or whichever measures faster in a short trial (recorded in config.sched)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams (each with its own context and scratch) the steps rotate over; 0 = per --sched trial")
+    return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`--gpus N` run bare: one child process per rank, started before the parent touches the
+    GPU.  Rank 0's stdout (the JSON line) is passed through."""
+    import torch
+    ndev = torch.cuda.device_count()          # does not initialise the GPU
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = os.environ.copy()
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if ndev < args.gpus:                   # rehearsal: ranks share the devices, gloo between them
+            env["UWSPR_BENCH_BACKEND"] = "gloo"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)
 
     import torch
     import torch.distributed as dist
@@ -101,42 +161,56 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
-    local = min(local, torch.cuda.device_count() - 1)   # rehearsal: several ranks on one GPU (gloo)
+    ndev = torch.cuda.device_count()
+    rehearsal = ndev < world                  # several ranks on one GPU (gloo)
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1 or os.environ.get("UWSPR_BENCH_FORCE_PG"):
+    backend = None
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        backend = os.environ.get("UWSPR_BENCH_BACKEND", "nccl")
+        backend = os.environ.get("UWSPR_BENCH_BACKEND", "gloo" if rehearsal else "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        world = dist.get_world_size()          # the ranks the collective library actually sees
 
-    B = args.frames
-    frames = G.synth.make_frames_torch(B, dev, seed=0xC0FFEE + 7919 * rank, snr_db=args.snr)
-    ns = max(1, args.streams)
-    lanes = []
-    for k in range(ns):
-        st = torch.cuda.Stream(device=dev)
-        cx = G.Context(device=local)
-        cx.set_stream(st.cuda_stream)
-        lanes.append({"stream": st, "ctx": cx,
-                      "cands": torch.empty(B * cx.maxfreqs * 48, dtype=torch.uint8, device=dev),
-                      "npk": torch.empty(B, dtype=torch.int32, device=dev),
-                      "out": torch.empty(B * N.DEMOD_DTYPE.itemsize, dtype=torch.uint8, device=dev),
-                      "slab": torch.empty((B, D.SLAB_BYTES), dtype=torch.uint8, device=dev)})
-    ctx, cands_t, npk_t, out_t = lanes[0]["ctx"], lanes[0]["cands"], lanes[0]["npk"], lanes[0]["out"]
-    torch.cuda.synchronize()
-    step_no = [0]
+    strong = args.total_frames > 0
+    B = D.local_count(args.total_frames, rank, world) if strong else args.frames
+    Bmax = D.local_count(args.total_frames, 0, world) if strong else B     # equal-sized (padded) shards
+    nb = NBATCH if B * 360000 * NBATCH < 40e9 else max(1, int(40e9 // (B * 360000)))
+    batches = [G.synth.make_frames_torch(B, dev, seed=0xC0FFEE + 7919 * rank + 104729 * k, snr_db=args.snr)
+               for k in range(nb)]
+    K = args.steps
 
-    def step():
-        ln = lanes[step_no[0] % ns]
-        step_no[0] += 1
+    def make_lanes(ns, fused):
+        os.environ["UWSPR_SCHED_FUSED"] = "1" if fused else "0"
+        lanes = []
+        for _ in range(ns):
+            st = torch.cuda.Stream(device=dev)
+            cx = G.Context(device=local)
+            cx.set_stream(st.cuda_stream)
+            lanes.append({"stream": st, "ctx": cx,
+                          "cands": torch.empty(B * cx.maxfreqs * 48, dtype=torch.uint8, device=dev),
+                          "npk": torch.empty(B, dtype=torch.int32, device=dev),
+                          "out": torch.empty(B * N.DEMOD_DTYPE.itemsize, dtype=torch.uint8, device=dev)})
+        return lanes
+
+    def close_lanes(lanes):
+        torch.cuda.synchronize()
+        for ln in lanes:
+            ln["ctx"].close()
+
+    # slabs of every step of a timed region: ONE gather at its end (off the per-step path)
+    slab_ring = torch.zeros((K, Bmax, D.SLAB_BYTES), dtype=torch.uint8, device=dev)
+
+    def step(lanes, i):
+        ln = lanes[i % len(lanes)]
         with torch.cuda.stream(ln["stream"]):
-            ln["ctx"].pipeline_batch_into(frames, ln["cands"], ln["npk"], ln["out"], max_per_frame=1)
-            ln["ctx"].pack_slabs_into(B, D.SLAB_K, ln["slab"])
-            return D.gather_slabs(ln["slab"], dst=0)
+            ln["ctx"].pipeline_batch_into(batches[i % nb], ln["cands"], ln["npk"], ln["out"], max_per_frame=1)
+            ln["ctx"].pack_slabs_into(B, D.SLAB_K, slab_ring[i % K])
 
     def barrier():
         torch.cuda.synchronize()
@@ -144,116 +218,144 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # timed region: HIP events only around the dominant kernel (K4); a second,
-    # untimed pass of the same K steps records every family for the breakdown
-    def prof_all(which):
-        for ln in lanes:
-            ln["ctx"].prof_enable(which)
-            ln["ctx"].prof_read()
-
-    def prof_sum():
-        tot = None
-        for ln in lanes:
-            p = ln["ctx"].prof_read()
-            if tot is None:
-                tot = p
-            else:
-                for k in p:
-                    for f in p[k]:
-                        tot[k][f] += p[k][f]
-        return tot
-
-    prof_all(("tonecorr",))
-    epoch = torch.cuda.Event(enable_timing=True)
-    epoch.record()
-    # the K4 launches of the first `prof_steps` timed steps carry HIP-event stamps (each stamped
-    # launch costs the queue a ~5 us bubble on either side: tools/trace_gaps.py); the roofline
-    # is taken over that window, `value` over all K steps
-    prof_steps = args.steps if args.prof_steps <= 0 else min(args.steps, args.prof_steps)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i == prof_steps:
-            for ln in lanes:
-                ln["ctx"].prof_enable(False)
-        gathered = step()
-    t_enq = time.perf_counter() - t0     # host time to enqueue the K steps (before any wait)
-    barrier()
-    dt = time.perf_counter() - t0
-    # K4 launches of different lanes may overlap in time: the family's busy time is
-    # the union of their [start, stop] intervals (HIP events, common epoch)
-    iv = []
-    for ln in lanes:
-        a, b = ln["ctx"].prof_intervals("tonecorr", epoch.cuda_event)
-        iv += list(zip(a, b))
-    iv.sort()
-    k4_busy_ms, cur_a, cur_b = 0.0, None, None
-    for a, b in iv:
-        if cur_b is None or a > cur_b:
-            if cur_b is not None:
-                k4_busy_ms += cur_b - cur_a
-            cur_a, cur_b = a, b
-        else:
-            cur_b = max(cur_b, b)
-    if cur_b is not None:
-        k4_busy_ms += cur_b - cur_a
-    prof_k4 = prof_sum()
-    prof_all(True)
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt_all_events = time.perf_counter() - t1
-    prof = prof_sum()
-    prof["tonecorr"] = prof_k4["tonecorr"]
-    prof_all(False)
-    # single-stream pass (untimed for `value`): K4 launch durations without other streams'
-    # kernels sharing the CUs; this is the figure a `--streams 1` rocprofv3 trace shows
-    k4_single = None
-    if ns > 1:
-        lanes[0]["ctx"].prof_enable(("tonecorr",))
-        lanes[0]["ctx"].prof_read()
-        n1 = min(args.steps, 20)
-        for _ in range(n1):
-            step_no[0] = 0
-            step()
+    def region(lanes, steps, gather=True):
+        """K steps between barrier + synchronize (+ the one gather); seconds, max over ranks."""
         barrier()
-        k4_single = lanes[0]["ctx"].prof_read()["tonecorr"]
-        k4_single["steps"] = n1
-        lanes[0]["ctx"].prof_enable(False)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64,
-                          device="cpu" if dist.get_backend() == "gloo" else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(lanes, i)
+        t_enq = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        g = D.gather_slabs(slab_ring.view(K * Bmax, D.SLAB_BYTES), dst=0) if gather else None
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if backend == "gloo" else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, t_enq, g
+
+    # ---- which schedule form / how many streams: a short trial, same on every rank ----
+    trials = {}
+    if args.sched == "auto" or args.streams <= 0:
+        cands = []
+        for fused in ((True, False) if args.sched == "auto" else ((args.sched == "fused"),)):
+            for ns in ((1, 2, 3) if args.streams <= 0 else (args.streams,)):
+                cands.append((fused, ns))
+        for fused, ns in cands:
+            lanes = make_lanes(ns, fused)
+            region(lanes, min(K, 6), gather=False)
+            trials[(fused, ns)] = min(region(lanes, K, gather=False)[0] for _ in range(2))
+            close_lanes(lanes)
+        if world > 1:   # every rank takes rank 0's choice
+            best = min(trials, key=trials.get)
+            ch = torch.tensor([int(best[0]), best[1]], dtype=torch.int64, device="cpu" if backend == "gloo" else dev)
+            dist.broadcast(ch, src=0)
+            fused, ns = bool(ch[0].item()), int(ch[1].item())
+        else:
+            fused, ns = min(trials, key=trials.get)
+    else:
+        fused, ns = args.sched == "fused", args.streams
+    lanes = make_lanes(ns, fused)
+    ctx = lanes[0]["ctx"]
+
+    for i in range(args.warmup):
+        step(lanes, i)
+    # ---- the timed region, R times ----
+    reps = []
+    for _ in range(max(1, args.repeats)):
+        dt, t_enq, gathered = region(lanes, K)
+        reps.append((dt, t_enq))
+    order = sorted(range(len(reps)), key=lambda r: reps[r][0])
+    dt, t_enq = reps[order[len(order) // 2]]
+    frames_per_step = args.total_frames if strong else world * B
+    rates = [frames_per_step * K / r[0] for r in reps]
+
+    # ---- per-kernel HIP-event times: single stream, same rotating batches (untimed for `value`) ----
+    ctx.prof_enable(True)
+    ctx.prof_read()
+    n1 = min(K, 20)
+    for i in range(n1):
+        step(lanes[:1], i)
+    barrier()
+    prof = ctx.prof_read()
+    ctx.prof_enable(False)
+    # the dominant kernel alone (events around it only: every recorded event is a marker packet)
+    ctx.prof_enable(("tonecorr",))
+    ctx.prof_read()
+    for i in range(n1):
+        step(lanes[:1], i)
+    barrier()
+    k4 = ctx.prof_read()["tonecorr"]
+    ctx.prof_enable(False)
 
     # ---- what the batch contained (outside the timed region) ----------------
-    cands = np.frombuffer(cands_t.cpu().numpy().tobytes(), N.CAND_DTYPE).reshape(B, -1)
-    npk = npk_t.cpu().numpy()
-    out = np.frombuffer(out_t.cpu().numpy().tobytes(), N.DEMOD_DTYPE).reshape(B, 1)
+    lanes[0]["ctx"].pipeline_batch_into(batches[0], lanes[0]["cands"], lanes[0]["npk"], lanes[0]["out"], max_per_frame=1)
+    torch.cuda.synchronize()
+    cands = np.frombuffer(lanes[0]["cands"].cpu().numpy().tobytes(), N.CAND_DTYPE).reshape(B, -1)
+    npk = lanes[0]["npk"].cpu().numpy()
+    out = np.frombuffer(lanes[0]["out"].cpu().numpy().tobytes(), N.DEMOD_DTYPE).reshape(B, 1)
     top_lin = np.array([cands[b, 0]["m_type"] == 0 if npk[b] > 0 else False for b in range(B)])
     live = npk > 0
     worth = out[:, 0]["worth_a_try"] > 0
-    fine_hyps = int(10 * live.sum() + 2 * (live & top_lin).sum() + 27 * worth.sum())
-    # the library skips the repeat of the stage winner in S1, S3 and S4 (stage-winner
-    # reuse): hypotheses resolved per step stay the reference's 39 per candidate, correlations run are fewer
+    nlive, nlin, nworth = int(live.sum()), int((live & top_lin).sum()), int(worth.sum())
+    # hypotheses the reference resolves per candidate: S0 5, S1 5, S2 2 (linear), S3 5, S4 5, S5 17
+    fine_hyps = 10 * nlive + 2 * nlin + 27 * nworth
+    # correlations the kernels run: the stage winner repeated by S1/S3/S4 is carried, S0's last lag is
+    # its first one symbol later (both forms); the fused form also carries try 0 of S5
     reuse_on = os.environ.get("UWSPR_K4_REUSE", "1") != "0"
-    fine_corr = fine_hyps - (int(live.sum() + 2 * worth.sum()) if reuse_on else 0)
-    # host tail: deinterleave + Fano of the batch's top candidates on the
-    # host cores; reported beside `value`, never inside the timed region
+    fine_corr = fine_hyps - ((nlive + 2 * nworth) if reuse_on else 0) - nlive - (nworth if (fused and reuse_on) else 0)
+    # binary32 operations those correlations need: 8 per sample, tone and hypothesis; the per-symbol
+    # phasor recurrences (6) only where the algorithm cannot share them (the two drift tries of S2)
+    ops_step = float(fine_corr) * OPS_MAC + 2.0 * nlin * OPS_PHASOR
+
     nthr = min(16, len(os.sched_getaffinity(0)))
     G.decode_batch(out[:8, 0], nthreads=nthr)
     t_h = time.perf_counter()
     _, _, okv = G.decode_batch(out[:, 0], nthreads=nthr)
     host_tail = {"records": int(B), "decoded": int(okv.sum()), "threads": nthr,
                  "records_per_s": B / (time.perf_counter() - t_h)}
-    decoded = int(okv[:64].sum())
 
-    frames_cpu = frames.cpu().numpy() if (rank == 0 and world == 1) else None
-    # the same batch handed over as HOST buffers (what a GNU Radio block would do):
-    # pageable H2D of the frames + D2H of every result, PCIe inclusive; never `value`
+    # ---- lazy jiggered shifts: only try 0 (fused form) ----
+    lazy = None
+    if rank == 0:
+        torch.cuda.synchronize()
+        lz = lanes if fused else make_lanes(1, True)
+        for ln in lz:
+            ln["ctx"].set_tries(1)
+        for i in range(5):
+            step(lz, i)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(K):
+            step(lz, i)
+        torch.cuda.synchronize()
+        dl = time.perf_counter() - t2
+        lz[0]["ctx"].pipeline_batch_into(batches[0], lz[0]["cands"], lz[0]["npk"], lz[0]["out"], max_per_frame=1)
+        torch.cuda.synchronize()
+        out1 = np.frombuffer(lz[0]["out"].cpu().numpy().tobytes(), N.DEMOD_DTYPE).reshape(B, 1)
+        _, _, ok1 = G.decode_batch(out1[:, 0], nthreads=nthr)
+        # the records try 0 did not decode get their other tries from uwspr_demod_resume
+        need = torch.from_numpy((~ok1.astype(bool)).astype(np.uint8)).to(dev)
+        t3 = time.perf_counter()
+        lz[0]["ctx"].demod_resume(batches[0], need, lz[0]["out"], max_per_frame=1)
+        torch.cuda.synchronize()
+        t_res = time.perf_counter() - t3
+        lazy = {"frames_per_s": B * K / dl, "ms_per_step": 1e3 * dl / K, "tries": 1, "streams": len(lz),
+                "decoded_by_try_0": int(ok1.sum()), "of": int(B), "resume_ms_for_the_rest": 1e3 * t_res,
+                "note": "fused form with uwspr_set_tries(1), this rank: the reference stops at its first decoding "
+                        "try (cc:457-490); the rest is produced on demand by uwspr_demod_resume"}
+        for ln in lz:
+            ln["ctx"].set_tries(17)
+        if not fused:
+            close_lanes(lz)
+            os.environ["UWSPR_SCHED_FUSED"] = "0"
+    if world > 1:
+        dist.barrier()
+
+    frames_cpu = batches[0].cpu().numpy() if (rank == 0 and world == 1) else None
+    # the same batch handed over as HOST buffers (what a GNU Radio block does per PDU batch):
+    # H2D of the frames + D2H of every result, PCIe inclusive; never `value`
     host_rate = None
     if frames_cpu is not None:
         ctx.pipeline_batch(frames_cpu, max_per_frame=1)
@@ -264,72 +366,75 @@ def main():
     if args.no_cpu:
         frames_cpu = None
     result = None
-    traffic = None
+    pmc = None
     tpath = os.path.join(ROOT, "profiles", "k4_traffic.json")
-    if os.path.exists(tpath) and B == 256:   # PMC-measured with rocprofv3 on this workload (separate passes)
-        traffic = json.load(open(tpath))
+    if os.path.exists(tpath):                 # PMC passes taken with rocprofv3 on this workload (tools/run_profiles.sh)
+        pmc = json.load(open(tpath))
     if rank == 0:
-        k4 = prof["tonecorr"]
+        k4_ms_step = k4["ms"] / n1
         k4_launch_ms = k4["ms"] / max(k4["launches"], 1)
-        k4_bytes_per_launch = fine_corr * HYP_BYTES / 6.0      # 6 K4 launches per step; correlations actually run
-        # achieved = algorithmic bytes of all K4 launches / time during which K4 was running
-        achieved = (fine_corr * HYP_BYTES * prof_steps) / (k4_busy_ms * 1e-3) / 1e9 if k4_busy_ms > 0 else 0.0
-        kern = {k: {"ms_per_step": v["ms"] / (prof_steps if k == "tonecorr" else args.steps),
-                    "launches_per_step": v["launches"] / (prof_steps if k == "tonecorr" else args.steps)}
-                for k, v in prof.items()}
+        achieved_tops = ops_step / (k4_ms_step * 1e-3) / 1e12 if k4_ms_step > 0 else 0.0
+        eff_gbs = fine_corr * HYP_BYTES / (k4_ms_step * 1e-3) / 1e9 if k4_ms_step > 0 else 0.0
+        kern = {k: {"ms_per_step": v["ms"] / n1, "launches_per_step": v["launches"] / n1} for k, v in prof.items()}
+        kern["tonecorr"] = {"ms_per_step": k4_ms_step, "launches_per_step": k4["launches"] / n1}
+        pm = (pmc or {}).get("fused" if fused else "staged", {}) if pmc else {}
         result = {
             "metric": "2-min WSPR frames decoded/sec (coarse+sync)",
-            "value": world * B * args.steps / dt,
+            "value": frames_per_step * K / dt,
             "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / K,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic .c2 frames (375 Hz, 45000 samples, "
-                                   "SNR %.0f dB) per GPU, flowgraph-default FDR grid (hbw=10, maxdrift=0, "
-                                   "threshold=10, all candidates searched), S0..S5 schedule + 17 soft-symbol "
-                                   "vectors for the top candidate of each frame, slab gather to rank 0"
-                                   % (B, args.snr),
-                       "frames_per_gpu": B, "candidates_per_frame_mean": float(npk.mean()),
+            "repeats": {"n": len(reps), "frames_per_s": rates, "min": min(rates), "median": float(np.median(rates)),
+                        "max": max(rates), "value_is": "median"},
+            "config": {"workload": "BASELINE configs[%d]: %s synthetic .c2 frames (375 Hz, 45000 samples, SNR %.0f dB)"
+                                   " per step, flowgraph-default FDR grid (hbw=10, maxdrift=0, threshold=10, all "
+                                   "candidates searched), S0..S5 schedule + 17 soft-symbol vectors for the top "
+                                   "candidate of each frame, slab packing every step, one slab gather to rank 0 per "
+                                   "timed region" % (3 if strong else 1,
+                                                     ("%d (sharded round-robin, %d per GPU)" % (args.total_frames, Bmax))
+                                                     if strong else ("%d per GPU" % B), args.snr),
+                       "frames_per_gpu": B, "distinct_batches": nb, "bytes_of_distinct_frames": nb * B * 360000,
+                       "candidates_per_frame_mean": float(npk.mean()),
                        "fine_hypotheses_per_step": fine_hyps,
                        "fine_correlations_run_per_step": fine_corr,
                        "coarse_hypotheses_per_step": int(npk.sum()) * 130 * ctx.info.cell_hyps,
-                       "top_candidate_decodes_in_first_64": decoded, "parallelism": "dp%d" % world,
-                       "streams_per_gpu": ns},
-            "roofline": {"kernel": "k4_tonecorr", "bound": "hbm", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic["bytes_per_launch"] if traffic else None,
-                         "traffic_source": traffic["source"] if traffic else None,
-                         "bytes_per_launch_algorithmic": k4_bytes_per_launch,
-                         "avg_launch_ms": k4_launch_ms,
-                         "k4_busy_ms_per_step": k4_busy_ms / prof_steps,
-                         "steps_with_k4_events": prof_steps,
-                         "k4_sum_of_launch_ms_per_step": k4["ms"] / prof_steps,
-                         "accounting": "launches from %d streams may overlap: achieved = bytes / union of the "
-                                       "launches' HIP-event intervals; bytes = 331950 B x the correlations the "
-                                       "launches actually run (config.fine_correlations_run_per_step), not the "
-                                       "reference's 39 per candidate" % ns,
-                         "single_stream": None if not k4_single else {
-                             "avg_launch_ms": k4_single["ms"] / max(k4_single["launches"], 1),
-                             "k4_ms_per_step": k4_single["ms"] / k4_single["steps"],
-                             "achieved": fine_corr * HYP_BYTES * k4_single["steps"] / (k4_single["ms"] * 1e-3) / 1e9,
-                             "frac": fine_corr * HYP_BYTES * k4_single["steps"] / (k4_single["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                             "note": "same step on one stream: launch durations comparable with "
-                                     "profiles/*_streams1 rocprofv3 kernel trace"},
-                         "fp32_tops": fine_corr * HYP_FLOP * prof_steps / (k4_busy_ms * 1e-3) / 1e12 if k4_busy_ms > 0 else 0.0,
-                         "fp32_nofma_peak_tops": FP32_NOFMA_PEAK_TOPS},
+                       "top_candidate_decodes": int(okv.sum()), "parallelism": "dp%d" % world,
+                       "sched": "fused (k6_sched)" if fused else "staged (k4_* + k5_fold_step)",
+                       "streams_per_gpu": ns,
+                       "trial_ms_per_step": {("%s x%d streams" % ("fused" if f else "staged", s)): 1e3 * v / K
+                                             for (f, s), v in trials.items()},
+                       "rehearsal_ranks_share_devices": bool(rehearsal), "backend": backend, "devices": min(ndev, world)},
+            "roofline": {"kernel": "k6_sched" if fused else "k4_* (6 launches)", "bound": "valu_fp32_nofma",
+                         "achieved": achieved_tops, "peak": FP32_NOFMA_PEAK_TOPS, "unit": "Top/s",
+                         "frac": achieved_tops / FP32_NOFMA_PEAK_TOPS,
+                         "traffic": pm.get("bytes_per_step"), "traffic_source": pm.get("source"),
+                         "valu_issue_utilisation_pmc": pm.get("valu_issue_utilisation"),
+                         "ops_per_step_algorithmic": ops_step,
+                         "kernel_ms_per_step": k4_ms_step, "avg_launch_ms": k4_launch_ms,
+                         "launches_per_step": k4["launches"] / n1,
+                         "accounting": "single stream, HIP events in the kernel's own dispatch packet, steps over "
+                                       "%d distinct batches; ops = 8 per sample, tone and hypothesis of the "
+                                       "correlations the launches run (config.fine_correlations_run_per_step) + 6 "
+                                       "for the per-symbol phasors of S2's two drift tries" % nb,
+                         "north_star_algorithmic": {
+                             "effective_sample_rate_GBs": eff_gbs, "x_hbm_peak": eff_gbs / HBM_PEAK_GBS,
+                             "note": "331950 B per correlation as if every hypothesis streamed its symbol windows "
+                                     "from HBM (SURVEY 8(d)); not an HBM utilisation: the measured fabric traffic is "
+                                     "`traffic`"}},
             "kernels": kern,
+            "lazy_s5": lazy,
             "host_pointer_frames_per_s_pcie_inclusive": host_rate,
             "host_tail_fano": host_tail,
-            "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
-            "ms_per_step_with_events_on_every_kernel": 1e3 * dt_all_events / args.steps,
+            "host_enqueue_ms_per_step": 1e3 * t_enq / K,
         }
 
     # ---- configs[2]: the (freq, lag, drift) sweep, N=1 only -----------------
-    if rank == 0 and world == 1 and not args.no_sweep:
+    if rank == 0 and world == 1 and not args.no_sweep and not strong:
         from gr_uwspr_amd import sweep as SW
         Bs = args.sweep_frames
-        del frames
+        del batches
         torch.cuda.empty_cache()
         fr2 = G.synth.make_frames_torch(Bs, dev, seed=99, snr_db=args.snr)
         H = Bs * 200
@@ -345,7 +450,7 @@ def main():
         sweep = {"workload": "BASELINE configs[2]: %d frames x 200 (freq,drift,lag) hypotheses, sync + 162 "
                              "soft symbols each" % Bs, "hypotheses": H, "north_star_bar_ms": 28.3}
 
-        def timed(fn, reps=3):
+        def timed(fn, ops_per_hyp, reps=3):
             fn()
             torch.cuda.synchronize()
             ctx.prof_enable(True)
@@ -358,26 +463,29 @@ def main():
             p2 = ctx.prof_read()
             ctx.prof_enable(False)
             k4ms = p2["tonecorr"]["ms"] / reps
+            tops = H * ops_per_hyp / (k4ms * 1e-3) / 1e12
             return {"ms_total": 1e3 * dts, "k4_ms": k4ms, "k5_ms": p2["fold"]["ms"] / reps,
                     "k4_launches": p2["tonecorr"]["launches"] / reps, "hyps_per_s": H / dts,
-                    "algorithmic_GBs_k4": H * HYP_BYTES / (k4ms * 1e-3) / 1e9,
-                    "frac_of_hbm_peak_k4": H * HYP_BYTES / (k4ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                    "fp32_tops_k4": tops, "frac_of_valu_peak_k4": tops / FP32_NOFMA_PEAK_TOPS,
+                    "effective_sample_rate_GBs_k4": H * HYP_BYTES / (k4ms * 1e-3) / 1e9,
+                    "x_hbm_peak_k4": H * HYP_BYTES / (k4ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
-        # grid form (uwspr_sync_grid): shared symbol windows + shared tone phasors
-        sweep["grid"] = timed(lambda: ctx.sync_grid(fr2, cent_t, df, dd, dl, into=(sync_t, sym_t)))
+        # grid form (uwspr_sync_grid): shared symbol windows, phasors shared by the 8 lags of a (freq, drift)
+        sweep["grid"] = timed(lambda: ctx.sync_grid(fr2, cent_t, df, dd, dl, into=(sync_t, sym_t)),
+                              OPS_MAC + OPS_PHASOR / 8.0)
         grid_sync = sync_t.clone()
         # flat form (uwspr_sync_sweep) on the same 204800 hypotheses, same order
         hy = G.sweep_grid_uniform(Bs, f_c=0.0, shift_c=368)
         hy = hy.reshape(Bs, 5, 8, 5).transpose(0, 1, 3, 2).reshape(-1).copy()
         hy_t = torch.from_numpy(np.frombuffer(hy.tobytes(), np.uint8).copy()).to(dev)
-        sweep["flat"] = timed(lambda: ctx.sync_sweep_into(fr2, hy_t, H, sync_t, sym_t))
-        sweep["flat"]["fp32_tops_k4"] = H * HYP_FLOP / (sweep["flat"]["k4_ms"] * 1e-3) / 1e12
+        sweep["flat"] = timed(lambda: ctx.sync_sweep_into(fr2, hy_t, H, sync_t, sym_t), OPS_MAC + OPS_PHASOR)
         sweep["grid_equals_flat_bitwise"] = bool(torch.equal(grid_sync, sync_t))
         result["sweep"] = sweep
 
     if rank == 0:
-        result["cpu_baseline"] = cpu_baseline(frames_cpu) if frames_cpu is not None else None
+        result["cpu_baseline"] = cpu_baseline(frames_cpu[:256]) if frames_cpu is not None else None
         print(json.dumps(result))
+        sys.stdout.flush()
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
