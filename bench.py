@@ -110,6 +110,7 @@ def parse_args():
     ap.add_argument("--snr", type=float, default=-20.0)
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-lazy", action="store_true", help="skip the lazy-S5 leg (profiling runs: only full-work launches)")
     ap.add_argument("--sweep-frames", type=int, default=1024)
     ap.add_argument("--sched", choices=("auto", "fused", "staged"), default="auto",
                     help="schedule form: k6_sched (one workgroup per candidate), the staged K4/K5 launches, "
@@ -318,7 +319,7 @@ def main():
 
     # ---- lazy jiggered shifts: only try 0 (fused form) ----
     lazy = None
-    if rank == 0:
+    if rank == 0 and not args.no_lazy:
         torch.cuda.synchronize()
         lz = lanes if fused else make_lanes(1, True)
         for ln in lz:
