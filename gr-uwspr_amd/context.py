@@ -229,6 +229,28 @@ class Context:
                                            C.c_void_p(out.ctypes.data)))
         return out
 
+    # ---- overlap-aware stream ingest (uwspr_stream_*) ----
+    def stream_open(self, hop=3375, max_frames=256):
+        self._chk(self.L.uwspr_stream_open(self.h, int(hop), int(max_frames)))
+
+    def stream_push(self, iq):
+        """Append (I,Q) samples (numpy [n,2] float32, or a torch CUDA tensor); -> frames ready."""
+        n = C.c_int(0)
+        if _is_torch(iq):
+            self._chk(self.L.uwspr_stream_push(self.h, C.c_void_p(iq.data_ptr()), iq.numel() // 2, N.DEVICE, C.byref(n)))
+        else:
+            a = np.ascontiguousarray(iq, np.float32)
+            self._chk(self.L.uwspr_stream_push(self.h, C.c_void_p(a.ctypes.data), a.size // 2, N.HOST, C.byref(n)))
+        return n.value
+
+    def stream_take(self, nframes, into):
+        """The next nframes frames into a torch CUDA float32 tensor [nframes, fl, 2]; -> stream
+        index of the first frame's first sample."""
+        pos = C.c_longlong(0)
+        fr = C.c_void_p()
+        self._chk(self.L.uwspr_stream_take(self.h, int(nframes), C.c_void_p(into.data_ptr()), C.byref(fr), C.byref(pos)))
+        return pos.value
+
     def set_tries(self, ntries):
         """Mode-2 tries per candidate the schedule calls produce (17 = all; fewer = lazy)."""
         self._chk(self.L.uwspr_set_tries(self.h, int(ntries)))

@@ -297,8 +297,10 @@ void launch_coarse(uwspr_ctx *c, int B) {
 int coarse_configure(const fdr_consts &f) {
   size_t need = coarse_lds_bytes(f);
   if (need > 160 * 1024) return -1;
+  // the attribute belongs to the function, not to a context: always the device maximum, so that a
+  // second context with a smaller tile cannot lower the limit under an earlier one
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k3_coarse),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)need);
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   return e == hipSuccess ? 0 : -2;
 }
 

@@ -115,6 +115,9 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->use_stage_grid = getenv("UWSPR_K4_STAGE_GRID") && atoi(getenv("UWSPR_K4_STAGE_GRID")) != 0;
   c->cap_slab = 0; c->d_slab = nullptr;
   c->sched_grid = getenv("UWSPR_SCHED_GRID") ? atoi(getenv("UWSPR_SCHED_GRID")) : 0;
+  c->cap_tmpc = 0; c->d_tmpc = nullptr; c->cap_tmpn = 0; c->d_tmpn = nullptr;
+  c->h_pin = nullptr; c->pin_busy[0] = c->pin_busy[1] = false;
+  c->d_stream[0] = c->d_stream[1] = nullptr; c->d_stream_frames = nullptr; c->st_hop = 0; c->st_maxf = 0; c->st_cap = 0; c->st_have = 0; c->st_cur = 0; c->st_pos = 0;
   c->ntries = UWSPR_NJIG; c->cap_pwin = 0; c->d_pwin = nullptr; c->cap_need = 0; c->d_need = nullptr;
   c->last_slots = 0; c->last_sched_B = 0; c->last_sched_per_frame = 0;
   c->cap_tabs = 0; c->d_tabs = nullptr; c->d_counter = nullptr; c->d_sched_stamps = nullptr; c->cap_sched_stamps = 0;
@@ -269,8 +272,9 @@ extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
   void *bufs[] = {c->d_window, c->d_twiddle, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
                   c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_cent,
-                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter, c->d_sched_stamps, c->d_pwin, c->d_need};
+                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter, c->d_sched_stamps, c->d_pwin, c->d_need, c->d_stream[0], c->d_stream[1], c->d_stream_frames, c->d_tmpc, c->d_tmpn};
   for (void *b : bufs) if (b) (void)hipFree(b);
+  if (c->h_pin) { (void)hipHostFree(c->h_pin); (void)hipEventDestroy(c->pin_ev[0]); (void)hipEventDestroy(c->pin_ev[1]); }
   for (auto &e : c->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -328,24 +332,56 @@ extern "C" int uwspr_synchronize(uwspr_ctx *c) {
   return UWSPR_OK;
 }
 
+// Host memory -> device through two pinned staging halves: the copy of piece k+1 into pinned memory
+// (host cores) overlaps the DMA of piece k (pageable hipMemcpy stages through one small internal
+// buffer and stalls on it).  Ends with everything enqueued on the context's stream.
+static int upload(uwspr_ctx *c, void *dst, const void *src, size_t bytes) {
+  const size_t PIECE = 8u << 20;
+  if (!c->h_pin) {
+    if (hipHostMalloc((void **)&c->h_pin, 2 * PIECE, hipHostMallocDefault) != hipSuccess) {
+      c->h_pin = nullptr;
+      (void)hipGetLastError();
+      HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+      return UWSPR_OK;
+    }
+    HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[0], hipEventDisableTiming));
+    HIPCHK(c, hipEventCreateWithFlags(&c->pin_ev[1], hipEventDisableTiming));
+    c->pin_busy[0] = c->pin_busy[1] = false;
+  }
+  size_t off = 0;
+  int k = 0;
+  while (off < bytes) {
+    const size_t n = bytes - off < PIECE ? bytes - off : PIECE;
+    char *half = (char *)c->h_pin + (size_t)(k & 1) * PIECE;
+    if (c->pin_busy[k & 1]) HIPCHK(c, hipEventSynchronize(c->pin_ev[k & 1]));   // its previous DMA is done
+    memcpy(half, (const char *)src + off, n);
+    HIPCHK(c, hipMemcpyAsync((char *)dst + off, half, n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->pin_ev[k & 1], c->stream));
+    c->pin_busy[k & 1] = true;
+    off += n;
+    k++;
+  }
+  return UWSPR_OK;
+}
+
 // frames -> device pointer (staged when they are host memory)
 static int frames_on_device(uwspr_ctx *c, const float *frames, int B, int where, const float **dev) {
   if (!frames || B <= 0) return fail(c, UWSPR_ERR_ARG, "frames=%p B=%d", (const void *)frames, B);
-  if (where == UWSPR_DEVICE) { *dev = frames; return UWSPR_OK; }
+  if (where == UWSPR_DEVICE || where == UWSPR_DEVICE_FRAMES) { *dev = frames; return UWSPR_OK; }
   if (where != UWSPR_HOST) return fail(c, UWSPR_ERR_ARG, "where=%d", where);
   const size_t bytes = (size_t)B * c->fc.fl * 2 * sizeof(float);
   size_t cap = c->cap_frames_bytes / sizeof(float);
   int rc = ensure(c, &c->d_frames, &cap, bytes / sizeof(float));
   c->cap_frames_bytes = cap * sizeof(float);
   if (rc) return rc;
-  HIPCHK(c, hipMemcpyAsync(c->d_frames, frames, bytes, hipMemcpyHostToDevice, c->stream));
+  if ((rc = upload(c, c->d_frames, frames, bytes))) return rc;
   *dev = c->d_frames;
   return UWSPR_OK;
 }
 
 static int copy_out(uwspr_ctx *c, void *dst, const void *src, size_t bytes, int where) {
   if (!dst || bytes == 0) return UWSPR_OK;
-  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, where == UWSPR_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dst, src, bytes, where != UWSPR_DEVICE ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, c->stream));
   return UWSPR_OK;
 }
 
@@ -399,6 +435,7 @@ static int ensure_fdr(uwspr_ctx *c, int B) {
   if (B <= c->cap_B) return UWSPR_OK;
   size_t cap;
   int rc;
+  c->cap_B = 0;   // a failed allocation below leaves no capacity behind that the null buffers cannot back
 #define GROW(ptr, elems) cap = 0; if (ptr) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(ptr)); ptr = nullptr; } \
   rc = ensure(c, &ptr, &cap, (size_t)(elems)); if (rc) return rc;
   GROW(c->d_ps, (size_t)B * f.n * f.band_w);
@@ -446,7 +483,7 @@ extern "C" int uwspr_fdr_batch(uwspr_ctx *c, const float *frames, int B, int whe
     if ((rc = copy_out(c, cands, c->d_cands, (size_t)B * c->fc.maxfreqs * sizeof(uwspr_candidate), where))) return rc;
     if ((rc = copy_out(c, npk, c->d_npk, (size_t)B * sizeof(int32_t), where))) return rc;
   }
-  if (where == UWSPR_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (where != UWSPR_DEVICE) HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWSPR_OK;
 }
 
@@ -719,20 +756,19 @@ extern "C" int uwspr_demod_batch(uwspr_ctx *c, const float *frames, int B, int w
   if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
   const uwspr_candidate *dc = cands;
   const int32_t *dn = npk;
-  uwspr_candidate *tmpc = nullptr; int32_t *tmpn = nullptr;
-  if (where == UWSPR_HOST) {
-    HIPCHK(c, hipMalloc((void **)&tmpc, (size_t)B * cand_stride * sizeof(uwspr_candidate)));
-    HIPCHK(c, hipMalloc((void **)&tmpn, (size_t)B * sizeof(int32_t)));
-    HIPCHK(c, hipMemcpyAsync(tmpc, cands, (size_t)B * cand_stride * sizeof(uwspr_candidate), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(tmpn, npk, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-    dc = tmpc; dn = tmpn;
+  const bool host_recs = where != UWSPR_DEVICE;   // UWSPR_DEVICE_FRAMES: frames on the device, records on the host
+  if (host_recs) {
+    if ((rc = ensure(c, &c->d_tmpc, &c->cap_tmpc, (size_t)B * cand_stride))) return rc;
+    if ((rc = ensure(c, &c->d_tmpn, &c->cap_tmpn, (size_t)B))) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_tmpc, cands, (size_t)B * cand_stride * sizeof(uwspr_candidate), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_tmpn, npk, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    dc = c->d_tmpc; dn = c->d_tmpn;
   }
   rc = run_schedule(c, d, B, dc, dn, cand_stride, max_per_frame);
-  if (!rc) rc = copy_out(c, out, c->d_dout, (size_t)B * max_per_frame * sizeof(uwspr_demod_out), where);
-  if (where == UWSPR_HOST) {
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipFree(tmpc); (void)hipFree(tmpn);
-  }
+  if (!rc) rc = copy_out(c, out, c->d_dout, (size_t)B * max_per_frame * sizeof(uwspr_demod_out), host_recs ? UWSPR_HOST : UWSPR_DEVICE);
+  if (host_recs) (void)hipStreamSynchronize(c->stream);
+  // uwspr_pack_slabs works on the buffers of a uwspr_pipeline_batch call only
+  c->last_per_frame = 0;
   return rc;
 }
 
@@ -755,9 +791,90 @@ extern "C" int uwspr_pipeline_batch(uwspr_ctx *c, const float *frames, int B, in
   if (c->cur_npk == c->d_npk && (rc = copy_out(c, npk, c->d_npk, (size_t)B * sizeof(int32_t), where))) return rc;
   if (c->cur_dout == c->d_dout &&
       (rc = copy_out(c, out, c->d_dout, (size_t)B * max_per_frame * sizeof(uwspr_demod_out), where))) return rc;
-  if (where == UWSPR_HOST) HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (where != UWSPR_DEVICE) HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWSPR_OK;
 }
+
+// ------------------------------------------------- overlap-aware stream ingest
+// frame f = stream samples [f hop, f hop + fl): overlapping source rows (no memcpy2D form), contiguous destination
+__global__ void k_cut_frames(const float2 *__restrict__ src, float2 *__restrict__ dst, int hop, int fl) {
+  const int f = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < fl; i += gridDim.x * blockDim.x)
+    dst[(size_t)f * fl + i] = src[(size_t)f * hop + i];
+}
+
+extern "C" int uwspr_stream_open(uwspr_ctx *c, int hop, int max_frames) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (hop <= 0 || hop > c->fc.fl || max_frames <= 0) return fail(c, UWSPR_ERR_ARG, "hop=%d max_frames=%d", hop, max_frames);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int k = 0; k < 2; k++) if (c->d_stream[k]) { (void)hipFree(c->d_stream[k]); c->d_stream[k] = nullptr; }
+  if (c->d_stream_frames) { (void)hipFree(c->d_stream_frames); c->d_stream_frames = nullptr; }
+  c->st_hop = hop; c->st_maxf = max_frames;
+  c->st_cap = (size_t)(2 * max_frames) * hop + c->fc.fl;     // samples: a full take plus as much again
+  for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc((void **)&c->d_stream[k], c->st_cap * 2 * sizeof(float)));
+  HIPCHK(c, hipMalloc((void **)&c->d_stream_frames, (size_t)max_frames * c->fc.fl * 2 * sizeof(float)));
+  c->st_cur = 0; c->st_have = 0; c->st_pos = 0;
+  return UWSPR_OK;
+}
+
+static int stream_ready(const uwspr_ctx *c) {
+  if (c->st_have < (size_t)c->fc.fl) return 0;
+  const size_t n = (c->st_have - c->fc.fl) / c->st_hop + 1;
+  return (int)(n < (size_t)c->st_maxf ? n : (size_t)c->st_maxf);
+}
+
+extern "C" int uwspr_stream_push(uwspr_ctx *c, const float *iq, int nsamples, int where, int *nready) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!c->d_stream[0]) return fail(c, UWSPR_ERR_ARG, "uwspr_stream_push before uwspr_stream_open");
+  if (nsamples < 0 || (nsamples > 0 && !iq)) return fail(c, UWSPR_ERR_ARG, "iq/nsamples");
+  if (c->st_have + (size_t)nsamples > c->st_cap)
+    return fail(c, UWSPR_ERR_ARG, "stream buffer full (%zu + %d > %zu samples): take frames first", c->st_have, nsamples, c->st_cap);
+  float *dst = c->d_stream[c->st_cur] + c->st_have * 2;
+  const size_t bytes = (size_t)nsamples * 2 * sizeof(float);
+  if (nsamples > 0) {
+    if (where == UWSPR_HOST) { if ((rc = upload(c, dst, iq, bytes))) return rc; }
+    else HIPCHK(c, hipMemcpyAsync(dst, iq, bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
+  c->st_have += nsamples;
+  if (nready) *nready = stream_ready(c);
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_stream_take(uwspr_ctx *c, int nframes, float *dev_dst, const float **frames, long long *first_pos) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!c->d_stream[0] || nframes <= 0 || nframes > stream_ready(c))
+    return fail(c, UWSPR_ERR_ARG, "uwspr_stream_take(%d): %d frames are complete", nframes, c->d_stream[0] ? stream_ready(c) : 0);
+  float *dst = dev_dst ? dev_dst : c->d_stream_frames;
+  const float *src = c->d_stream[c->st_cur];
+  hipLaunchKernelGGL(k_cut_frames, dim3(44, nframes), dim3(256), 0, c->stream, (const float2 *)src, (float2 *)dst,
+                     c->st_hop, c->fc.fl);
+  HIPCHK(c, hipGetLastError());
+  // what later frames still need moves to the front of the other buffer
+  const size_t used = (size_t)nframes * c->st_hop, rest = c->st_have - used;
+  if (rest) HIPCHK(c, hipMemcpyAsync(c->d_stream[c->st_cur ^ 1], src + used * 2, rest * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  c->st_cur ^= 1;
+  c->st_have = rest;
+  if (first_pos) *first_pos = c->st_pos;
+  c->st_pos += (long long)used;
+  if (frames) *frames = dst;
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_stream_reset(uwspr_ctx *c, long long pos) {
+  int rc = ready(c);
+  if (rc) return rc;
+  c->st_have = 0; c->st_pos = pos;
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_device_alloc(size_t bytes, void **ptr) {
+  if (!ptr) return UWSPR_ERR_ARG;
+  return hipMalloc(ptr, bytes) == hipSuccess ? UWSPR_OK : UWSPR_ERR_NOMEM;
+}
+extern "C" void uwspr_device_free(void *ptr) { if (ptr) (void)hipFree(ptr); }
 
 extern "C" int uwspr_set_tries(uwspr_ctx *c, int ntries) {
   int rc = ready(c);

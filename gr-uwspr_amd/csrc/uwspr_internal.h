@@ -146,6 +146,11 @@ struct uwspr_ctx {
   bool use_fused; bool sched_nopad; int sched_grid;
   size_t cap_tabs; float *d_tabs;     // [sched_grid][2][5][4][256](c, s) phasor tables
   int *d_counter;                     // candidate queue head of the running launch
+  size_t cap_tmpc; uwspr_candidate *d_tmpc; size_t cap_tmpn; int32_t *d_tmpn;   // uwspr_demod_batch: host records staged
+  // pinned staging for host -> device copies (two halves, ping-pong)
+  void *h_pin; hipEvent_t pin_ev[2]; bool pin_busy[2];
+  // overlap-aware stream ingest (uwspr_stream_*): the stream tail lives on the device
+  float *d_stream[2]; float *d_stream_frames; int st_hop, st_maxf, st_cur; size_t st_cap, st_have; long long st_pos;
   int ntries;                         // mode-2 tries per candidate a schedule call produces (uwspr_set_tries)
   size_t cap_pwin; float *d_pwin;     // [nslots][162][4] winner magnitudes kept for uwspr_demod_resume (ntries < 17)
   size_t cap_need; uint8_t *d_need;   // staging of the resume mask

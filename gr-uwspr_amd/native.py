@@ -28,7 +28,7 @@ HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
             "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 NSYM, NSLM, NK0, NIFR, NJIG = 162, 125, 26, 5, 17
-HOST, DEVICE = 0, 1
+HOST, DEVICE, DEVICE_FRAMES = 0, 1, 2
 LINEAR, NONLINEAR = 0, 1
 
 
@@ -143,7 +143,8 @@ class Prof(C.Structure):
 ABI_SYMBOLS = [
     "uwspr_ctx_create", "uwspr_ctx_destroy", "uwspr_last_error", "uwspr_status_string",
     "uwspr_get_info", "uwspr_set_stream", "uwspr_synchronize", "uwspr_frontend_batch",
-    "uwspr_frontend_taps", "uwspr_fdr_batch",
+    "uwspr_frontend_taps", "uwspr_stream_open", "uwspr_stream_push", "uwspr_stream_take", "uwspr_stream_reset",
+    "uwspr_device_alloc", "uwspr_device_free", "uwspr_fdr_batch",
     "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
     "uwspr_sync_sweep", "uwspr_sync_grid", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
     "uwspr_pipeline_batch", "uwspr_set_tries", "uwspr_demod_resume", "uwspr_pack_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
@@ -189,6 +190,13 @@ def lib():
     L.uwspr_synchronize.argtypes = [vp]
     L.uwspr_frontend_batch.argtypes = [vp, vp, ip, ip, ip, vp]
     L.uwspr_frontend_taps.argtypes = [vp, ip]
+    L.uwspr_stream_open.argtypes = [vp, ip, ip]
+    L.uwspr_stream_push.argtypes = [vp, vp, ip, ip, C.POINTER(C.c_int)]
+    L.uwspr_stream_take.argtypes = [vp, ip, vp, C.POINTER(vp), C.POINTER(C.c_longlong)]
+    L.uwspr_stream_reset.argtypes = [vp, C.c_longlong]
+    L.uwspr_device_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.uwspr_device_free.argtypes = [vp]
+    L.uwspr_device_free.restype = None
     L.uwspr_fdr_batch.argtypes = [vp, vp, ip, ip, vp, vp]
     L.uwspr_fdr_read_spectrum.argtypes = [vp, ip, vp, vp, vp, vp, vp]
     L.uwspr_fdr_keep_syncgrid.argtypes = [vp, ip]

@@ -41,7 +41,9 @@ typedef enum {
   UWSPR_ERR_NODEVICE = -7     /* no usable gfx950 device: there is NO CPU fallback */
 } uwspr_status;
 
-enum { UWSPR_HOST = 0, UWSPR_DEVICE = 1 };
+/* UWSPR_DEVICE_FRAMES (uwspr_fdr_batch, uwspr_demod_batch, uwspr_pipeline_batch): the frames are device
+ * memory (e.g. what uwspr_stream_take returned), every other pointer of the call is host memory. */
+enum { UWSPR_HOST = 0, UWSPR_DEVICE = 1, UWSPR_DEVICE_FRAMES = 2 };
 enum { UWSPR_LINEAR = 0, UWSPR_NONLINEAR = 1 };   /* enum Modes, lib/candidate_t.h:36 */
 
 #define UWSPR_NSYM 162      /* symbols per frame */
@@ -153,6 +155,28 @@ int uwspr_synchronize(uwspr_ctx *ctx);
 int uwspr_frontend_batch(uwspr_ctx *ctx, const float *audio, int B, int nin, int where,
                          float *frames_out);
 int uwspr_frontend_taps(float *taps_re_im, int cap_pairs);
+
+/* ---- overlap-aware stream ingest ----------------------- */
+/* sliding_window_stream_to_pdu::work (lib/sliding_window_stream_to_pdu_impl.cc:97-138) cuts the
+ * 375 S/s stream into frames of fl samples that start every hop = shift*fs = 3375 samples: 41625 of
+ * a frame's 45000 samples are its predecessor's.  Handing whole frames to the calls below uploads
+ * every sample 13 times; through this interface every sample crosses PCIe ONCE and the frames are
+ * cut on the device:
+ *   uwspr_stream_open(ctx, hop, max_frames)        hop in samples; at most max_frames per take
+ *   uwspr_stream_push(ctx, iq, n, where, &nready)  append n (I,Q) pairs; nready = complete frames waiting
+ *   uwspr_stream_take(ctx, k, dev_dst, &frames, &pos)  the next k frames as [k][fl] (I,Q) pairs in device
+ *       memory (dev_dst, or NULL = a buffer of the context, valid until the next take); pos =
+ *       stream index of the first one's first sample; consumes k*hop samples.  Use the result with
+ *       where = UWSPR_DEVICE or UWSPR_DEVICE_FRAMES.
+ *   uwspr_stream_reset(ctx, pos)                   drop what is buffered; the next sample pushed has index pos
+ * Frame k of the stream is bit for bit the frame the reference's PDU k carries. */
+int uwspr_stream_open(uwspr_ctx *ctx, int hop, int max_frames);
+int uwspr_stream_push(uwspr_ctx *ctx, const float *iq, int nsamples, int where, int *nready);
+int uwspr_stream_take(uwspr_ctx *ctx, int nframes, float *dev_dst, const float **frames, long long *first_pos);
+int uwspr_stream_reset(uwspr_ctx *ctx, long long pos);
+/* device memory for callers without a HIP runtime of their own (the block mirror's frame hand-over) */
+int uwspr_device_alloc(size_t bytes, void **ptr);
+void uwspr_device_free(void *ptr);
 
 /* ---- coarse search: FDR_impl::transform, FDR_impl.cc:214-456 ------------ */
 /* cands: [B][maxfreqs] records; npk: [B].  Same candidate order, fields and

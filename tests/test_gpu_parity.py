@@ -631,3 +631,49 @@ def test_lazy_tries_and_resume_equal_the_eager_schedule(G, frames, vec):
         assert got.tobytes() == full[:, 0].tobytes()
     finally:
         c.close()
+
+
+def test_stream_push_frames_equal_whole_frame_calls(G, oracle):
+    """uwspr_stream_*: a continuous stream pushed in ragged pieces, frames cut on the device every
+    3375 samples (sliding_window_stream_to_pdu::work, cc:113-135): every sample is uploaded once,
+    and the frames -- hence every byte the pipeline produces from them -- equal the whole-frame
+    calls on host frames sliced from the same stream."""
+    import torch
+    hop, fl = 3375, 45000
+    nfr = 6
+    base = G.synth.make_frames(2, seed=4242, snr_db=-18.0)
+    stream = np.concatenate([base[0], base[1][: (nfr - 1) * hop + 1000]], axis=0)   # fl + 5 hops + a bit
+    want = np.stack([stream[k * hop: k * hop + fl] for k in range(nfr)])
+    c = G.Context()
+    try:
+        ref_c, ref_o = c.pipeline_batch(want, max_per_frame=2)
+        c.stream_open(hop, 4)
+        got = torch.empty((nfr, fl, 2), dtype=torch.float32, device="cuda")
+        rng = np.random.default_rng(1)
+        pos, taken = 0, 0
+        while taken < nfr:
+            n = int(rng.integers(1, 9000))
+            ready = c.stream_push(stream[pos: pos + n])
+            pos += min(n, len(stream) - pos)
+            while ready > 0 and taken < nfr:
+                k = min(ready, nfr - taken, 1 + taken % 3)
+                first = c.stream_take(k, got[taken: taken + k])
+                assert first == taken * hop
+                taken += k
+                ready = c.stream_push(stream[0:0])
+        c.synchronize()
+        assert got.cpu().numpy().tobytes() == want.tobytes()
+        cd, od = c.pipeline_batch(got, max_per_frame=2)
+        for a, b in zip(ref_c, cd):
+            assert a.tobytes() == b.tobytes()
+        assert od.tobytes() == ref_o.tobytes()
+        # frames on the device, records on the host (UWSPR_DEVICE_FRAMES)
+        cands = np.zeros((nfr, c.maxfreqs), G.native.CAND_DTYPE)
+        npk = np.zeros(nfr, np.int32)
+        import ctypes as C
+        c._chk(c.L.uwspr_fdr_batch(c.h, C.c_void_p(got.data_ptr()), nfr, G.native.DEVICE_FRAMES,
+                                   C.c_void_p(cands.ctypes.data), C.c_void_p(npk.ctypes.data)))
+        for b in range(nfr):
+            assert cands[b, :npk[b]].tobytes() == ref_c[b].tobytes()
+    finally:
+        c.close()
