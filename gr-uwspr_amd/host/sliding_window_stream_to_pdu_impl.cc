@@ -16,12 +16,12 @@ class sliding_window_stream_to_pdu_impl : public sliding_window_stream_to_pdu {
  public:
   sliding_window_stream_to_pdu_impl(int fs, int fl, int shift, int C)
       : block("sliding_window_stream_to_pdu"), d_fs(fs), d_fl(fl), d_shift(shift),
-        d_cap((size_t)C * fl), d_count(0) {
+        d_cap((size_t)C * fl), d_count(0), d_popped(0) {
     message_port_register_out("out");  // cc:54-55
   }
   int work(int noutput_items, const gr_complex *in) override {
     for (int i = 0; i < noutput_items; i++) {
-      if (d_buf.size() == d_cap) d_buf.pop_front();  // boost::circular_buffer overwrite
+      if (d_buf.size() == d_cap) { d_buf.pop_front(); d_popped++; }  // boost::circular_buffer overwrite
       d_buf.push_back(in[i]);                        // cc:108-110
     }
     d_count += noutput_items;
@@ -29,10 +29,12 @@ class sliding_window_stream_to_pdu_impl : public sliding_window_stream_to_pdu {
       const int hop = d_shift * d_fs;
       auto pdu = std::make_shared<samples_pdu>();
       pdu->samples.resize(d_fl);
+      pdu->stream_pos = d_popped;      // index of the frame's first sample in the input stream
       for (int i = 0; i < hop; i++) {  // peek + pop, cc:117-124
         pdu->samples[i] = d_buf.front();
         d_buf.pop_front();
       }
+      d_popped += hop;
       for (int i = 0; i < d_fl - hop; i++) pdu->samples[hop + i] = d_buf[i];  // cc:126-129
       message_port_pub("out", pdu);  // cc:133
       d_count -= hop;                // cc:134
@@ -44,6 +46,7 @@ class sliding_window_stream_to_pdu_impl : public sliding_window_stream_to_pdu {
   int d_fs, d_fl, d_shift;
   size_t d_cap;
   long d_count;
+  long long d_popped;   // samples that have left the front of the ring
   std::deque<gr_complex> d_buf;
 };
 

@@ -2,9 +2,11 @@
 // gr::uwspr::sync_and_demodulate (lib/sync_and_demodulate_impl.cc:315-534):
 // candidates PDU in, one 7-byte blob PDU out per decoded candidate, in candidate
 // order.  The refinement schedule S0..S5 runs on the GPU for all candidates of
-// the frame in one uwspr_demod_batch call; the gate/retry/Fano loop (cc:457-490)
+// the frame(s) in one uwspr_demod_batch call (set_batch(n): n candidates PDUs per call; frames
+// that FDR left on the device are read there); the gate/retry/Fano loop (cc:457-490)
 // is replayed on the host by uwspr_decode_batch (uwspr_decode_candidate per record).
 #include <stdio.h>
+#include <string.h>
 #include <time.h>
 
 #include <stdexcept>
@@ -49,49 +51,77 @@ class sync_and_demodulate_impl : public sync_and_demodulate {
     }
   }
   unsigned framecount() const override { return d_framecount; }
+  void set_batch(int n) override { d_batch = n < 1 ? 1 : n; }
+  void flush() override { run(); }
 
  private:
   void demodulate(message_sptr msg) {
     auto in = std::dynamic_pointer_cast<const candidates_pdu>(msg);
     if (!in || !in->samples || (int)in->samples->samples.size() != d_fl) return;
-    const int npk = in->npk;
-    if (npk <= 0) return;
-    std::vector<float> frame((size_t)d_fl * 2);
-    for (int i = 0; i < d_fl; i++) {
-      frame[2 * (size_t)i] = in->samples->samples[i].real();      // cc:344-345
-      frame[2 * (size_t)i + 1] = in->samples->samples[i].imag();
+    if (in->npk <= 0) return;
+    d_pending.push_back(in);
+    if ((int)d_pending.size() >= d_batch) run();
+  }
+  void run() {
+    const int B = (int)d_pending.size();
+    if (B == 0) return;
+    int per = 0;
+    for (auto &p : d_pending) per = p->npk > per ? p->npk : per;
+    std::vector<uwspr_candidate> cands((size_t)B * per);
+    std::vector<int32_t> npk(B);
+    for (int b = 0; b < B; b++) {
+      npk[b] = d_pending[b]->npk;
+      for (int j = 0; j < npk[b]; j++) cands[(size_t)b * per + j] = d_pending[b]->candidates[j];
     }
-    std::vector<uwspr_demod_out> out(npk);
-    int32_t n = npk;
-    int rc = uwspr_demod_batch(d_ctx, frame.data(), 1, UWSPR_HOST, in->candidates.data(), &n, npk,
-                               npk, out.data());
+    std::vector<uwspr_demod_out> out((size_t)B * per);
+    // FDR left the frames of its batch in device memory, one after the other: if these PDUs point
+    // at such a run the schedule reads them there (no second upload); else the payloads go up
+    bool on_device = d_pending[0]->dev.ptr != nullptr;
+    for (int b = 1; b < B && on_device; b++)
+      on_device = d_pending[b]->dev.ptr == d_pending[0]->dev.ptr + (size_t)b * d_fl * 2;
+    int rc;
+    if (on_device) {
+      rc = uwspr_demod_batch(d_ctx, d_pending[0]->dev.ptr, B, UWSPR_DEVICE_FRAMES, cands.data(), npk.data(), per,
+                             per, out.data());
+    } else {
+      std::vector<float> frames((size_t)B * d_fl * 2);
+      for (int b = 0; b < B; b++)   // cc:344-345: std::complex<float> is the (I,Q) pair
+        memcpy(&frames[(size_t)b * d_fl * 2], d_pending[b]->samples->samples.data(), (size_t)d_fl * 2 * sizeof(float));
+      rc = uwspr_demod_batch(d_ctx, frames.data(), B, UWSPR_HOST, cands.data(), npk.data(), per, per, out.data());
+    }
     if (rc != UWSPR_OK)
       throw std::runtime_error(std::string("uwspr.sync_and_demodulate: ") + uwspr_last_error(d_ctx));
     // cc:389: the candidates are independent, so their Fano runs go to the host
-    // cores together; results are published in candidate order as the reference does
-    std::vector<int8_t> msgs((size_t)npk * 7);
-    std::vector<uint8_t> got(npk);
-    if (uwspr_decode_batch(out.data(), npk, 0, msgs.data(), nullptr, got.data()) < 0)
+    // cores together; results are published in frame, then candidate order as the reference does
+    const int n = B * per;
+    std::vector<int8_t> msgs((size_t)n * 7);
+    std::vector<uint8_t> got(n);
+    if (uwspr_decode_batch(out.data(), n, 0, msgs.data(), nullptr, got.data()) < 0)
       throw std::runtime_error("uwspr.sync_and_demodulate: decode_batch");
-    for (int j = 0; j < npk; j++) {
-      if (!got[j]) continue;
-      const int8_t *m7 = &msgs[(size_t)j * 7];
-      d_framecount++;  // cc:492
-      if (d_log) {
-        const candidate_t &c = in->candidates[j];
-        fprintf(d_log, "Frame: %u\nBaseband freq is %2.2f Hz\n(6 Hz) SNR is %2.2f dB\nData: ",
-                d_framecount, c.freq, c.snr);
-        for (int i = 0; i < 7; i++) fprintf(d_log, "%02x", (unsigned)(unsigned char)m7[i]);
-        fprintf(d_log, "\n\n");
-        fflush(d_log);
+    for (int b = 0; b < B; b++) {
+      for (int j = 0; j < npk[b]; j++) {
+        if (!got[(size_t)b * per + j]) continue;
+        const int8_t *m7 = &msgs[((size_t)b * per + j) * 7];
+        d_framecount++;  // cc:492
+        if (d_log) {
+          const candidate_t &c = d_pending[b]->candidates[j];
+          fprintf(d_log, "Frame: %u\nBaseband freq is %2.2f Hz\n(6 Hz) SNR is %2.2f dB\nData: ",
+                  d_framecount, c.freq, c.snr);
+          for (int i = 0; i < 7; i++) fprintf(d_log, "%02x", (unsigned)(unsigned char)m7[i]);
+          fprintf(d_log, "\n\n");
+          fflush(d_log);
+        }
+        auto blob = std::make_shared<blob_pdu>();
+        for (int i = 0; i < 7; i++) blob->bytes[i] = m7[i];
+        message_port_pub("out", blob);  // cc:528-530
       }
-      auto blob = std::make_shared<blob_pdu>();
-      for (int i = 0; i < 7; i++) blob->bytes[i] = m7[i];
-      message_port_pub("out", blob);  // cc:528-530
     }
+    d_pending.clear();
   }
 
   uwspr_ctx *d_ctx;
+  int d_batch = 1;
+  std::vector<std::shared_ptr<const candidates_pdu> > d_pending;
   int d_fl;
   unsigned d_framecount;
   FILE *d_log;

@@ -43,11 +43,22 @@ typedef std::shared_ptr<const message> message_sptr;
 
 struct samples_pdu : message {
   std::vector<gr_complex> samples;  /* fl samples; I = real, Q = imag */
+  /* PDU metadata (the dictionary in the car of a real PDU, NIL in the reference): index of samples[0]
+   * in the framer's input stream, -1 = unknown.  Lets FDR upload only the samples it has not seen. */
+  long long stream_pos = -1;
+};
+/* A frame that already lives in device memory: [fl] (I,Q) binary32 pairs.  `keep` owns the memory
+ * (returned to the producer's pool when the last reference goes), so the handle stays valid however
+ * late the consumer runs -- what a real GNU Radio message queue needs. */
+struct device_frame {
+  const float *ptr = nullptr;
+  std::shared_ptr<void> keep;
 };
 struct candidates_pdu : message {
   std::shared_ptr<const samples_pdu> samples;  /* the input vector is re-used, FDR_impl.cc:450 */
   int npk;
   std::vector<candidate_t> candidates;
+  device_frame dev;   /* metadata: the same frame on the device (FDR has it there anyway); ptr == nullptr: none */
 };
 struct blob_pdu : message {
   signed char bytes[7];

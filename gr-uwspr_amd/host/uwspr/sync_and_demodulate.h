@@ -13,6 +13,10 @@ class UWSPR_API sync_and_demodulate : virtual public block {
    * ./messagelog.txt (sync_and_demodulate_impl.cc:98-108,506-526). Default off. */
   virtual void set_messagelog(bool on) = 0;
   virtual unsigned framecount() const = 0;
+  /* GPU batching knob (not in the reference): collect n candidates PDUs per device call; blobs are
+   * published in arrival order.  Default 1 = one call per PDU. */
+  virtual void set_batch(int n) = 0;
+  virtual void flush() = 0;
   sync_and_demodulate() : block("sync_and_demodulate") {}
 };
 }  // namespace uwspr

@@ -3,7 +3,7 @@
 // the resampler):  stream -> sliding_window_stream_to_pdu(375,45000,9,2)
 //   -> FDR(375,45000,256,0,200,10,1500,10) -> sync_and_demodulate(375,45000,256,0,200,1500)
 //   -> WSPR_unpacker() -> sink
-// modes:  framer | errors | decode <file.c2>
+// modes:  framer | errors | decode <file.c2> | stream <file.c2>
 #include <stdio.h>
 #include <string.h>
 
@@ -77,7 +77,55 @@ static int decode(const char *path) {
   return 0;
 }
 
+// A continuous stream (the .c2 frame twice, 5 hops apart, on a noise floor) through the chain twice:
+// batched (FDR / sync 4 PDUs per call: stream ingest, frames handed over on the device) and one
+// PDU per call (whole-frame uploads).  Prints both result lists; they must be identical.
+static int stream(const char *path) {
+  std::vector<float> iq(2 * 45000);
+  if (uwspr_c2_read(path, iq.data(), nullptr, nullptr) != 0) { printf("cannot read %s\n", path); return 2; }
+  const int hop = 3375, nfr = 8, total = 45000 + (nfr - 1) * hop;
+  std::vector<gr_complex> s(total);
+  unsigned lcg = 12345u;
+  for (int i = 0; i < total; i++) {
+    lcg = lcg * 1664525u + 1013904223u; const float a = ((lcg >> 8) & 0xffff) / 65536.0f - 0.5f;
+    lcg = lcg * 1664525u + 1013904223u; const float b = ((lcg >> 8) & 0xffff) / 65536.0f - 0.5f;
+    s[i] = gr_complex(0.05f * a, 0.05f * b);
+  }
+  for (int i = 0; i < 45000; i++) s[i] += gr_complex(iq[2 * i], iq[2 * i + 1]);
+  for (int i = 0; i + 5 * hop < total && i < 45000; i++) s[i + 5 * hop] += 0.7f * gr_complex(iq[2 * i], iq[2 * i + 1]);
+  for (int pass = 0; pass < 2; pass++) {
+    auto sw = sliding_window_stream_to_pdu::make(375, 45000, 9, 2);
+    auto fdr = FDR::make(375, 45000, 256, 0, 200, 10, 1500, 10);
+    auto sad = sync_and_demodulate::make(375, 45000, 256, 0, 200, 1500);
+    auto unp = WSPR_unpacker::make();
+    message_sink cands, texts;
+    block::msg_connect(sw.get(), "out", fdr.get(), "in");
+    block::msg_connect(fdr.get(), "out", sad.get(), "in");
+    block::msg_connect(fdr.get(), "out", &cands, "in");
+    block::msg_connect(sad.get(), "out", unp.get(), "in");
+    block::msg_connect(unp.get(), "out", &texts, "in");
+    if (pass == 0) { fdr->set_batch(4); sad->set_batch(4); }
+    // the framer emits at most one PDU per work() call (cc:113): feed it hop-sized pieces
+    for (int off = 0; off < total; off += 1125) sw->work(off + 1125 <= total ? 1125 : total - off, s.data() + off);
+    fdr->flush();
+    sad->flush();
+    int ondev = 0;
+    printf("pass %d pdus %zu\n", pass, cands.received.size());
+    for (auto &m : cands.received) {
+      auto c = std::dynamic_pointer_cast<const candidates_pdu>(m);
+      ondev += c->dev.ptr != nullptr;
+      printf("p%d pos %lld npk %d", pass, c->samples->stream_pos, c->npk);
+      for (auto &k : c->candidates) printf(" | %d %.9f %.9f %d", k.m_type, k.freq, k.sync, k.shift);
+      printf("\n");
+    }
+    for (auto &m : texts.received) printf("p%d text %s\n", pass, std::dynamic_pointer_cast<const text_pdu>(m)->text.c_str());
+    printf("pass %d frames %u on_device %d\n", pass, sad->framecount(), ondev);
+  }
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc >= 3 && !strcmp(argv[1], "stream")) return stream(argv[2]);
   if (argc >= 2 && !strcmp(argv[1], "framer")) return framer();
   if (argc >= 2 && !strcmp(argv[1], "errors")) return errors();
   if (argc >= 3 && !strcmp(argv[1], "decode")) return decode(argv[2]);
