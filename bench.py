@@ -364,6 +364,32 @@ def main():
         for _ in range(3):
             ctx.pipeline_batch(frames_cpu, max_per_frame=1)
         host_rate = 3 * B / (time.perf_counter() - t2)
+    # ... and as a continuous 375 S/s STREAM (uwspr_stream_*): every step uploads only the B x 3375 new
+    # samples (pinned staging), the frames are cut on the device, every result goes back to the host
+    stream_rate = None
+    if frames_cpu is not None:
+        hop = 3375
+        rng = np.random.default_rng(3)
+        chunk = (0.5 * rng.standard_normal((B * hop, 2))).astype(np.float32)
+        ctx.stream_open(hop, B)
+        ctx.stream_push(frames_cpu[0][: 45000 - hop])
+        fr_t = torch.empty((B, 45000, 2), dtype=torch.float32, device=dev)
+        ln0 = lanes[0]
+
+        def stream_step():
+            ctx.stream_push(chunk)
+            ctx.stream_take(B, fr_t)
+            with torch.cuda.stream(ln0["stream"]):
+                ln0["ctx"].pipeline_batch_into(fr_t, ln0["cands"], ln0["npk"], ln0["out"], max_per_frame=1)
+            ctx.synchronize()
+            return ln0["npk"].cpu(), ln0["cands"].cpu(), ln0["out"].cpu()
+
+        if ln0["ctx"] is ctx:
+            stream_step()
+            t2 = time.perf_counter()
+            for _ in range(5):
+                stream_step()
+            stream_rate = 5 * B / (time.perf_counter() - t2)
     if args.no_cpu:
         frames_cpu = None
     result = None
@@ -427,6 +453,7 @@ def main():
             "kernels": kern,
             "lazy_s5": lazy,
             "host_pointer_frames_per_s_pcie_inclusive": host_rate,
+            "host_stream_frames_per_s_pcie_inclusive": stream_rate,
             "host_tail_fano": host_tail,
             "host_enqueue_ms_per_step": 1e3 * t_enq / K,
         }

@@ -332,11 +332,15 @@ extern "C" int uwspr_synchronize(uwspr_ctx *c) {
   return UWSPR_OK;
 }
 
-// Host memory -> device through two pinned staging halves: the copy of piece k+1 into pinned memory
-// (host cores) overlaps the DMA of piece k (pageable hipMemcpy stages through one small internal
-// buffer and stalls on it).  Ends with everything enqueued on the context's stream.
+// Host memory -> device.  Small pieces (a stream push: a few MB) go through two pinned staging halves,
+// the copy of piece k+1 into pinned memory overlapping the DMA of piece k, and return with the
+// transfer merely enqueued; whole batches of frames are left to the runtime's pageable path.
 static int upload(uwspr_ctx *c, void *dst, const void *src, size_t bytes) {
   const size_t PIECE = 8u << 20;
+  if (bytes > 4 * PIECE) {   // a whole batch of frames: one host thread's memcpy into pinned memory (~10 GB/s)
+    HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));   // would be slower than the runtime's own staging (measured 57 k vs 87 k frames/s)
+    return UWSPR_OK;
+  }
   if (!c->h_pin) {
     if (hipHostMalloc((void **)&c->h_pin, 2 * PIECE, hipHostMallocDefault) != hipSuccess) {
       c->h_pin = nullptr;
