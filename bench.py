@@ -111,6 +111,7 @@ def parse_args():
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-lazy", action="store_true", help="skip the lazy-S5 leg (profiling runs: only full-work launches)")
+    ap.add_argument("--no-host-legs", action="store_true", help="skip the host-pointer and stream-ingest legs (profiling runs)")
     ap.add_argument("--sweep-frames", type=int, default=1024)
     ap.add_argument("--sched", choices=("auto", "fused", "staged"), default="auto",
                     help="schedule form: k6_sched (one workgroup per candidate), the staged K4/K5 launches, "
@@ -354,7 +355,7 @@ def main():
     if world > 1:
         dist.barrier()
 
-    frames_cpu = batches[0].cpu().numpy() if (rank == 0 and world == 1) else None
+    frames_cpu = batches[0].cpu().numpy() if (rank == 0 and world == 1 and not args.no_host_legs) else None
     # the same batch handed over as HOST buffers (what a GNU Radio block does per PDU batch):
     # H2D of the frames + D2H of every result, PCIe inclusive; never `value`
     host_rate = None

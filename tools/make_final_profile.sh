@@ -10,7 +10,7 @@ echo "# build at commit $H (+ working tree); MI355X gfx950, ROCm 7.2; script: to
 for form in fused staged; do
 echo
 echo "# ===== schedule form: $form ====="
-echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-sweep --sched $form --streams 1 --repeats 1 --steps 20 --warmup 3"
+echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-sweep --no-lazy --no-host-legs --sched $form --streams 1 --repeats 1 --steps 20 --warmup 3"
 python3 tools/prof_summary.py $P/trace_$form
 echo "# separate PMC passes (--steps 3 --warmup 1); FETCH_SIZE/WRITE_SIZE in KB per launch, UNCORRECTED"
 python3 tools/prof_summary.py $P/pmc_fetch_$form | sed -n '/counters/,$p'

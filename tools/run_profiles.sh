@@ -8,7 +8,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 hipcc --offload-arch=gfx950 -O2 tools/fetch_calib.hip -o /tmp/fetch_calib 2>/dev/null
 for form in fused staged; do
-  B="python3 bench.py --no-cpu --no-sweep --no-lazy --sched $form --streams 1 --repeats 1"
+  B="python3 bench.py --no-cpu --no-sweep --no-lazy --no-host-legs --sched $form --streams 1 --repeats 1"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$form -- $B --steps 20 --warmup 3 > $OUT/trace_$form.log 2>&1
   timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch_$form -- $B --steps 3 --warmup 1 > $OUT/pmc_fetch_$form.log 2>&1
   timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write_$form -- $B --steps 3 --warmup 1 > $OUT/pmc_write_$form.log 2>&1
