@@ -106,14 +106,10 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
       // delta[] = {-1.5,-0.5,0.5,1.5} * (float)(375/256), cc:148 (exact in binary32)
       const float delta = ((float)(tone0 + j) - 1.5f) * 1.46484375f;
       const double ang = kTwoPiDt * (double)(fp + delta);
-#ifdef K4_EXPERIMENT_FASTTRIG   // timing experiment only: NOT the reference arithmetic
-      cd[j] = __cosf((float)ang); sd[j] = __sinf((float)ang);
-#else
       double sn, cs;
       sincos(ang, &sn, &cs);
       cd[j] = (float)cs;
       sd[j] = (float)sn;
-#endif
     }
   }
 
@@ -135,10 +131,6 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
 
   float2 stage[NLD];
   auto load_chunk = [&](int c) {
-#ifdef K4_EXPERIMENT_NOLOAD   // timing experiment only
-    for (int t = 0; t < NLD; t++) stage[t] = make_float2(0.5f + c, 0.25f);
-    return;
-#endif
     if (interior) {
 #pragma unroll
       for (int t = 0; t < NLD; t++) stage[t] = src[t][16 * c];
@@ -547,14 +539,10 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
       fp = gy.f0 + gy.slmc;
     }
     const float delta = ((float)tone - 1.5f) * 1.46484375f;
-#if defined(K4R_EXP) && (K4R_EXP & 4)   // timing experiment 4: no binary64 sincos
-    cd = 0.999f + 1e-6f * fp; sd = 0.01f + delta * 1e-6f;
-#else
     double sn, cs;
     sincos(kTwoPiDt * (double)(fp + delta), &sn, &cs);
     cd = (float)cs;
     sd = (float)sn;
-#endif
   }
 
   // ---- cooperative loader: load j of a slot = pair 4j + lane/16, sample lane%16
@@ -593,7 +581,6 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   };
 
   // prologue: slots 0..Q -- all their loads in flight together (one memory round trip, not Q+1)
-#if !(defined(K4R_EXP) && (K4R_EXP & 8))   // timing experiment 8: no prologue loads
   {
     float2 pro[Q + 1][4];
 #pragma unroll
@@ -609,7 +596,6 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
       store_slot(sl);
     }
   }
-#endif
 
   // ring positions of slots c..c+Q as this lane's row addresses
   int sa[M];   // dword offsets into `lds` (kept as integers so the reads stay ds_read)
@@ -627,12 +613,8 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
     for (int ch = 0; ch < 16; ch++) {
       // in flight during the chunk's arithmetic (the last chunk re-fetches the last slot: no
       // branch here or after the arithmetic, or the compiler sinks the arithmetic past it)
-#if !(defined(K4R_EXP) && (K4R_EXP & 1))   // timing experiment 1: no global loads in the walk
       load_slot(min(ch + Q + 1, NSLOT - 1));
-#endif
-#if !(defined(K4R_EXP) && (K4R_EXP & 2))   // timing experiment 2: no fences / LDS stores in the walk
       wave_lds_fence();                      // the slots written so far are visible
-#endif
       // Two samples per read: STEP is even, so sample k + STEP l of an even step k and its
       // successor sit in one 16-byte-aligned LDS word pair -- one ds_read_b128 per lag and two
       // steps (an LDS read costs the SIMD about as much issue time as five arithmetic
@@ -675,10 +657,8 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
         for (int l = 0; l < NL; l++) vc[l] = vn[l];
       }
       // slot ch is finished with: its position takes slot ch + Q + 1, and the addresses rotate
-#if !(defined(K4R_EXP) && (K4R_EXP & 2))
       wave_lds_fence();
       store_slot(wpos);
-#endif
       wpos = (wpos + 1 == M) ? 0 : wpos + 1;
       const int first = sa[0];
 #pragma unroll

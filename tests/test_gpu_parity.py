@@ -677,3 +677,23 @@ def test_stream_push_frames_equal_whole_frame_calls(G, oracle):
             assert cands[b, :npk[b]].tobytes() == ref_c[b].tobytes()
     finally:
         c.close()
+
+
+def test_two_contexts_with_different_coarse_tiles(G, oracle, frames):
+    """The coarse-search kernel's dynamic-LDS limit is a property of the function, not of a context:
+    a second context with a smaller tile (cf = 500) must not lower it under an earlier one (defaults),
+    and a larger one (hbw = 40, maxdrift = 2) created later must work as well."""
+    a = G.Context()
+    b = G.Context(cf=500)
+    c = G.Context(halfbandwidth=40, maxdrift=2)
+    try:
+        for ctx, kw in ((a, {}), (c, {"halfbandwidth": 40, "maxdrift": 2}), (b, {"cf": 500}), (a, {})):
+            got = ctx.fdr_batch(frames[:2])
+            f = oracle.FDR(**kw)
+            for bb in range(2):
+                exp = f.transform(frames[bb])
+                assert len(got[bb]) == len(exp)
+                for x, e in zip(got[bb], exp):
+                    cand_equal(x, e)
+    finally:
+        a.close(); b.close(); c.close()
