@@ -32,10 +32,21 @@ struct cpx { float r, i; };
 UWSPR_HD int rev3(int x) { return ((x & 1) << 2) | (x & 2) | ((x >> 2) & 1); }
 UWSPR_HD int rev6(int x) { return (rev3(x & 7) << 3) | rev3((x >> 3) & 7); }
 
-// LDS image index of position p used by both exchanges (pad 1 per 32 to
-// spread the strided accesses over banks).
-UWSPR_HD int xidx(int p) { return p + (p >> 5); }
-constexpr int XCHG_LEN = 512 + 16;
+// LDS image index of position p used by both exchanges: an XOR swizzle of the low five bits by
+// the high four, chosen so that all four access patterns are bank-conflict free on gfx950 (8-byte
+// elements: ds_write_b64 is served in groups of 16 lanes over 32 banks -> index mod 16 must differ
+// within a group; ds_read_b64 in groups of 32 lanes over 64 banks -> index mod 32):
+//   write A  varies p8 p7 p6 p5          -> index bits 2 1 3 0
+//   read  B  varies p7 p6 p2 p1 p0       -> index bits 4 3 (2 1 0 xor const)
+//   write B  varies p6 p2 p1 p0          -> index bits 3 (2 1 0 xor const)
+//   read  C  varies p4..p0               -> index bits 4..0 xor const
+// (a one-per-32 padding left read B with up to four-way conflicts: the exchanges, not the
+// arithmetic, bounded K1).
+UWSPR_HD int xidx(int p) {
+  return p ^ ((((p >> 7) & 1) << 4) | (((p >> 6) & 1) << 3) | (((p >> 8) & 1) << 2) | (((p >> 7) & 1) << 1) |
+              ((p >> 5) & 1));
+}
+constexpr int XCHG_LEN = 512;
 
 // u,v <- u + w*v, u - w*v   (general twiddle)
 UWSPR_HD void bfly(cpx &u, cpx &v, float wr, float wi) {

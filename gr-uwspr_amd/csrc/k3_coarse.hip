@@ -15,6 +15,8 @@
 //    same path).  Identical sequences give bit-identical metrics, so each distinct
 //    one is evaluated once (130 x 38 = 4940 evaluations per candidate, not 16380)
 //    and the selection below reads it back through a hypothesis -> sequence map.
+//    The sequences are stored as 16-bit byte offsets into the LDS tile (k3_seq_entry) and stay in
+//    HBM/L2 (82 KB per ifr window), read 16 B = 8 symbols at a time two loads ahead.
 //  * The spectrogram window the candidate can touch is staged once into LDS as
 //    float4 {sqrt ps[row][c-3], [c-1], [c+1], [c+3]} per (row, centre column c):
 //    one ds_read_b128 gather per symbol instead of four gathers + four sqrt.
@@ -28,6 +30,7 @@
 // tile read and the 48-byte candidate record stays in LDS.
 // Roofline: LDS-gather / VALU bound; HBM traffic is the tile once (~60 KB).
 #include <algorithm>
+#include <cstdlib>
 
 #include "uwspr_internal.h"
 
@@ -36,18 +39,40 @@
 namespace uwspr {
 
 constexpr int K3_THREADS = 1024;
+// Offset sequences: per (ifr row, distinct sequence) K3_SEQ_WORDS words = 168 x u16 (162 used; 16-B loads), entry k =
+// byte offset of the symbol's float4 in the tile relative to the float4 of (row k0 + 2*32*(k/32), the
+// cell's own centre column): ((2*(k mod 32))*tp + (ifd-ifr)[k] - off_min) * 16, tp = tile row pitch in
+// float4.  Segments of 32 symbols keep that below 65536 for every pitch the 160 KB tile allows (<= 29).
+// Pitch: consecutive lanes are consecutive sequences of one cell (same row: offsets differ by < 16
+// float4, no conflict inside a ds_read_b128 lane group), but a group that straddles two cells reads
+// rows one apart, i.e. float4 indices tp + (difference of offsets) apart: with tp = nc = 13 every
+// pair three columns apart collides (27 % of the kernel's LDS cycles); tp = 8 (mod 16) leaves only the
+// pairs eight columns apart (UWSPR_K3_PITCH=24; see coarse_tile_pitch() for why it is not the default).
+constexpr int K3_SEQ_WORDS = 84, K3_SEG_SYMS = 32;
+__host__ __device__ inline uint32_t k3_seq_entry(int k, int off, int off_min, int nc) {
+  return (uint32_t)((2 * (k % K3_SEG_SYMS)) * nc + off - off_min) * 16u;
+}
+typedef uint32_t k3_u4 __attribute__((ext_vector_type(4)));   // HIP's uint4 class cannot live behind an address-space pointer
+constexpr int K3_SLICE_PITCH = 68;   // floats per 64-hypothesis slice of the expanded metrics (16-B pad)
 
-struct k3_lds_layout { size_t tile, uoff, sync, umap, total; };
+// lane ^ 1 and lane ^ 2 inside a quad: DPP quad_perm, no LDS round trip
+__device__ __forceinline__ float quad_swap1(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float quad_swap2(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
+struct k3_lds_layout { size_t tile, sync, umap, total; };
 __host__ __device__ inline k3_lds_layout k3_layout(const fdr_consts &f) {
   k3_lds_layout l;
   l.tile = 0;
-  l.uoff = l.tile + (size_t)f.n * f.nc * 16;
-  l.sync = l.uoff + (f.uoff_global ? 0 : (size_t)UWSPR_NIFR * f.umax * 41 * 4);
+  l.sync = l.tile + (size_t)f.n * f.tp * 16;
   l.umap = l.sync + (size_t)UWSPR_NIFR * UWSPR_NK0 * f.umax * 4;
   l.total = l.umap + (((size_t)UWSPR_NIFR * f.cell_hyps * 2 + 15) & ~(size_t)15);
   // after the evaluation the tile + offset-table range is reused for the expanded
-  // metrics [ntot rounded to 64] + 3 floats per 64-value slice: grow it if needed
-  const size_t reuse = ((size_t)((f.ntot + 63) & ~63) + 3 * (size_t)((f.ntot + 63) >> 6)) * 4;
+  // metrics [64-value slices at K3_SLICE_PITCH] + 3 floats per slice: grow it if needed
+  const size_t reuse = ((size_t)K3_SLICE_PITCH + 3) * (size_t)((f.ntot + 63) >> 6) * 4;
   if (reuse > l.sync) {
     const size_t extra = (reuse - l.sync + 15) & ~(size_t)15;
     l.sync += extra; l.umap += extra; l.total += extra;
@@ -61,8 +86,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
     const int32_t *__restrict__ work, float *__restrict__ syncgrid, int grid_cap) {
   extern __shared__ __align__(16) unsigned char smem[];
   const k3_lds_layout lay = k3_layout(f);
-  float4 *tile = reinterpret_cast<float4 *>(smem + lay.tile);        // [n][nc]
-  uint32_t *uoff = reinterpret_cast<uint32_t *>(smem + lay.uoff);    // [5][umax][41]
+  float4 *tile = reinterpret_cast<float4 *>(smem + lay.tile);        // [n][tp], nc used per row
   float *syncbuf = reinterpret_cast<float *>(smem + lay.sync);       // [130][umax]
   uint16_t *umap = reinterpret_cast<uint16_t *>(smem + lay.umap);    // [5][cell_hyps]
 
@@ -88,14 +112,14 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   for (int idx = tid; idx < f.n * f.nc; idx += K3_THREADS) {
     int row = idx / f.nc, ci = idx - row * f.nc;
     const float *pr = psb + (size_t)row * f.band_w + c0 + ci;
-    tile[idx] = make_float4(ieee_sqrtf(pr[-3]), ieee_sqrtf(pr[-1]), ieee_sqrtf(pr[1]),
-                            ieee_sqrtf(pr[3]));
+    tile[row * f.tp + ci] = make_float4(ieee_sqrtf(pr[-3]), ieee_sqrtf(pr[-1]), ieee_sqrtf(pr[1]),
+                                        ieee_sqrtf(pr[3]));
   }
-  const int nuw = UWSPR_NIFR * f.umax * 41;
-  // (large cf / maxdrift: the sequences stay in HBM/L2 and only the tile and the metrics use LDS)
-  if (!f.uoff_global)
-    for (int idx = tid; idx < nuw; idx += K3_THREADS) uoff[idx] = uoff_tab[(size_t)r0 * f.umax * 41 + idx];
-  const uint32_t *uo_base = f.uoff_global ? uoff_tab + (size_t)r0 * f.umax * 41 : uoff;
+  // the offset sequences stay in HBM/L2 (82 KB would not leave room for the tile) and are read
+  // through a GLOBAL-address-space pointer: a generic one makes them flat loads, which count on
+  // lgkmcnt as well and turn every LDS wait of the gather loop into a wait for L2
+  typedef const k3_u4 __attribute__((address_space(1))) *seq_ptr;
+  const seq_ptr uo_base = (seq_ptr)(uintptr_t)(uoff_tab + (size_t)r0 * f.umax * K3_SEQ_WORDS);
   for (int idx = tid; idx < UWSPR_NIFR * f.cell_hyps; idx += K3_THREADS)
     umap[idx] = umap_tab[(size_t)r0 * f.cell_hyps + idx];
   __syncthreads();
@@ -104,49 +128,50 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
 #endif
 
   // ---- one lane per (cell, distinct offset sequence) -------------------------
-  const int nc2 = 2 * f.nc;
+  const int segstep = 2 * K3_SEG_SYMS * f.tp * 16;
   const int neval = UWSPR_NIFR * UWSPR_NK0 * f.umax;
   for (int g = tid; g < neval; g += K3_THREADS) {
     const int cell = g / f.umax, u = g - cell * f.umax;
     const int ifr_i = cell / UWSPR_NK0, k0 = cell - ifr_i * UWSPR_NK0;
-    const uint32_t *ot = uo_base + (ifr_i * f.umax + u) * 41;
-    int idx = k0 * f.nc + ifr_i - f.off_min;  // tile index of (row k0, offset 0)
+    // the sequence as 16-bit BYTE offsets into the tile, relative to the (row k0, this cell's
+    // centre) float4 of the current 32-symbol segment (k3_seq_entry): a gather address is one add
+    const seq_ptr ot = uo_base + (ifr_i * f.umax + u) * (K3_SEQ_WORDS / 4);
+    const char *tb = reinterpret_cast<const char *>(tile) + (k0 * f.tp + ifr_i) * 16;
     float ss = 0.0f, pw = 0.0f;
-    // Software pipeline: the 4 gathers of symbol group k4+1 (and the offset word
-    // of group k4+2) are in flight while group k4 is accumulated, so the LDS
-    // latency is paid once per 4 symbols instead of once per symbol.
-    float4 Pc[4], Pn[4];
-    uint32_t w1 = ot[0], w2 = ot[1];
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) {
-      Pc[kk] = tile[idx + (int)(int8_t)(w1 >> (8 * kk))];
-      idx += nc2;  // kindex = k0 + 2k (cc:197)
-    }
-#pragma unroll
-    for (int k4 = 0; k4 < 41; k4++) {
-      w1 = w2;
-      if (k4 + 2 < 41) w2 = ot[k4 + 2];
-      if (k4 + 1 < 41) {
-#pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-          if (4 * (k4 + 1) + kk < UWSPR_NSYM) {
-            Pn[kk] = tile[idx + (int)(int8_t)(w1 >> (8 * kk))];
-            idx += nc2;
-          }
-        }
-      }
+    // Software pipeline over groups of 4 symbols: the 4 gathers of the next group are in flight
+    // while this one is accumulated, and the offset words (16 B = 8 symbols per load) are
+    // requested two loads ahead of their use: neither the LDS nor the L2 latency is exposed.
+    float4 Pa[4], Pb[4];
+    k3_u4 wa = ot[0], wb = ot[1], wc = ot[2];
+    auto gather2 = [&](float4 *P, uint32_t w) {
+      P[0] = *reinterpret_cast<const float4 *>(tb + (w & 0xffffu));
+      P[1] = *reinterpret_cast<const float4 *>(tb + (w >> 16));
+    };
+    auto accumulate = [&](const float4 *P, int k, int count) {
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
-        const int k = 4 * k4 + kk;
-        if (k < UWSPR_NSYM) {
-          const float4 P = Pc[kk];
-          const float cm = (P.y + P.w) - (P.x + P.z);
-          ss = pr3_bit(k) ? ss + cm : ss - cm;  // (2*pr3[k]-1)*cm, cc:207
-          pw = pw + P.x; pw = pw + P.y; pw = pw + P.z; pw = pw + P.w;  // cc:209
+        if (kk < count) {
+          const float4 q = P[kk];
+          const float cm = (q.y + q.w) - (q.x + q.z);
+          ss = pr3_bit(k + kk) ? ss + cm : ss - cm;  // (2*pr3[k]-1)*cm, cc:207
+          pw = pw + q.x; pw = pw + q.y; pw = pw + q.z; pw = pw + q.w;  // cc:209
         }
       }
+    };
+    gather2(Pa, wa.x); gather2(Pa + 2, wa.y);
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) Pc[kk] = Pn[kk];
+    for (int k8 = 0; k8 < K3_SEQ_WORDS / 4; k8++) {
+      const int k = 8 * k8;   // symbols k..k+3 are in Pa
+      if (k + 4 < UWSPR_NSYM) { gather2(Pb, wa.z); gather2(Pb + 2, wa.w); }
+      accumulate(Pa, k, UWSPR_NSYM - k);
+      if (k + 8 < UWSPR_NSYM) {
+        if ((k + 8) % K3_SEG_SYMS == 0) tb += segstep;   // next segment's base
+        gather2(Pa, wb.x);
+        if (k + 10 < UWSPR_NSYM) gather2(Pa + 2, wb.y);
+      }
+      if (k + 4 < UWSPR_NSYM) accumulate(Pb, k + 4, UWSPR_NSYM - k - 4);
+      wa = wb; wb = wc;
+      if (k8 + 3 < K3_SEQ_WORDS / 4) wc = ot[k8 + 3];
     }
     syncbuf[g] = ieee_divf(ss, pw);  // cc:357,390
   }
@@ -176,36 +201,54 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   //      rises with v for best > 0 and falls for best < 0), so a slice whose
   //      extreme value fails cannot contain an acceptance and is skipped -- and
   //      only slices that may accept are scanned value by value with ballots.
-  float *full = reinterpret_cast<float *>(smem);                       // [ntot]
-  float *ssum = full + ((f.ntot + 63) & ~63);                          // [nslice][3]
+  float *full = reinterpret_cast<float *>(smem);                       // [nslice][K3_SLICE_PITCH]
   const int nslice = (f.ntot + 63) >> 6;
+  float *ssum = full + (size_t)nslice * K3_SLICE_PITCH;                // [nslice][3]
   {
-    const int lane = tid & 63;
+    // (1a) expansion, consecutive lanes = consecutive hypotheses (conflict-free LDS traffic):
     // thread walks g = tid, tid + 1024, ...: (cell, h) advance by carry, no division in the loop
     const int qstep = K3_THREADS / hc, rstep = K3_THREADS - qstep * hc;
     int cell = tid / hc, h = tid - cell * hc;
-    const float ninf = -__builtin_inff(), pinf = __builtin_inff();
-    for (int g = tid; g < nslice * 64; g += K3_THREADS) {
-      const bool in = g < f.ntot;
+    for (int g = tid; g < f.ntot; g += K3_THREADS) {
       const int ifr_i = cell / UWSPR_NK0;  // constant divisor
-      const float v = in ? syncbuf[cell * f.umax + umap[ifr_i * hc + h]] : 0.0f;
-      const bool lin = h < f.nlin;
-      // NaN never satisfies a predicate: keep it out of the extremes
-      const bool use = in && (v == v);
-      float mlin = (use && lin) ? v : ninf;
-      float mxnl = (use && !lin) ? v : ninf;
-      float mnnl = (use && !lin) ? v : pinf;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        mlin = fmaxf(mlin, __shfl_xor(mlin, o));
-        mxnl = fmaxf(mxnl, __shfl_xor(mxnl, o));
-        mnnl = fminf(mnnl, __shfl_xor(mnnl, o));
-      }
-      if (in) full[g] = v;
-      const int sl = g >> 6;
-      if (lane == 0) { ssum[3 * sl] = mlin; ssum[3 * sl + 1] = mxnl; ssum[3 * sl + 2] = mnnl; }
+      full[g + (g >> 6) * (K3_SLICE_PITCH - 64)] = syncbuf[cell * f.umax + umap[ifr_i * hc + h]];
       cell += qstep; h += rstep;
       if (h >= hc) { h -= hc; cell += 1; }
+    }
+  }
+  __syncthreads();
+  {
+    // (1b) slice summaries: four lanes per slice, 16 consecutive values each (four ds_read_b128;
+    // the 4-float pad per slice keeps the 16 lanes of a read group on distinct banks), reduced in
+    // registers and then over the quad with two DPP steps -- not 18 ds_bpermute per 64 values
+    const float ninf = -__builtin_inff(), pinf = __builtin_inff();
+    for (int sl = tid >> 2; sl < nslice; sl += K3_THREADS / 4) {
+      const int qd = tid & 3;
+      const int g0 = sl * 64 + qd * 16;
+      const float4 *src = reinterpret_cast<const float4 *>(full + (size_t)sl * K3_SLICE_PITCH + qd * 16);
+      float vv[16];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float4 q4 = src[i];
+        vv[4 * i] = q4.x; vv[4 * i + 1] = q4.y; vv[4 * i + 2] = q4.z; vv[4 * i + 3] = q4.w;
+      }
+      int h = g0 % hc;
+      float mlin = ninf, mxnl = ninf, mnnl = pinf;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const float v = vv[i];
+        // NaN never satisfies a predicate: keep it out of the extremes
+        const bool use = (g0 + i < f.ntot) && (v == v);
+        const bool lin = h < f.nlin;
+        mlin = fmaxf(mlin, (use && lin) ? v : ninf);
+        mxnl = fmaxf(mxnl, (use && !lin) ? v : ninf);
+        mnnl = fminf(mnnl, (use && !lin) ? v : pinf);
+        h = (h + 1 == hc) ? 0 : h + 1;
+      }
+      mlin = fmaxf(mlin, quad_swap1(mlin)); mlin = fmaxf(mlin, quad_swap2(mlin));
+      mxnl = fmaxf(mxnl, quad_swap1(mxnl)); mxnl = fmaxf(mxnl, quad_swap2(mxnl));
+      mnnl = fminf(mnnl, quad_swap1(mnnl)); mnnl = fminf(mnnl, quad_swap2(mnnl));
+      if (qd == 0) { ssum[3 * sl] = mlin; ssum[3 * sl + 1] = mxnl; ssum[3 * sl + 2] = mnnl; }
     }
   }
   __syncthreads();
@@ -236,7 +279,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
       // exact scan of slice `hit`
       const int g = hit * 64 + tid;
       const bool in = g < f.ntot;
-      const float v = in ? full[g] : 0.0f;
+      const float v = in ? full[hit * K3_SLICE_PITCH + tid] : 0.0f;
       const bool lin = in && (g % hc) < f.nlin;
       int start = 0;
       for (;;) {
@@ -283,6 +326,16 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
 }
 
 size_t coarse_lds_bytes(const fdr_consts &f) { return k3_layout(f).total; }
+int coarse_seq_words() { return K3_SEQ_WORDS; }
+int coarse_tile_pitch(fdr_consts f) {
+  // measured: pitch 24 instead of 13 made the kernel 3 % faster for 61 KB more LDS (the conflicts
+  // are not what bounds the gather loop) -- the compact tile stays the default
+  int want = f.nc;
+  if (const char *e = getenv("UWSPR_K3_PITCH")) { if (atoi(e) >= f.nc) want = atoi(e); }
+  f.tp = want;
+  return k3_layout(f).total <= 160 * 1024 ? want : f.nc;
+}
+uint32_t coarse_seq_entry(int k, int off, int off_min, int nc) { return k3_seq_entry(k, off, off_min, nc); }
 
 void launch_coarse(uwspr_ctx *c, int B) {
   const fdr_consts &f = c->fc;

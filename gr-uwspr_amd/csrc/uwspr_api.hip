@@ -16,6 +16,9 @@
 namespace uwspr {
 int coarse_configure(const fdr_consts &f);
 size_t coarse_lds_bytes(const fdr_consts &f);
+int coarse_seq_words();
+int coarse_tile_pitch(fdr_consts f);
+uint32_t coarse_seq_entry(int k, int off, int off_min, int nc);
 }  // namespace uwspr
 
 using namespace uwspr;
@@ -236,22 +239,20 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
     }
     f.umax = std::max(f.umax, (int)uniq_of[r].size());
   }
-  // [ifr][u][k4] words of 4 x int8; rows with fewer distinct sequences repeat sequence 0
-  std::vector<uint32_t> offw((size_t)f.n_ifr * f.umax * 41);
+  // [ifr][u][84] words of 2 x u16 tile byte offsets (coarse_seq_entry); rows with fewer distinct
+  // sequences repeat sequence 0
+  f.tp = coarse_tile_pitch(f);
+  const int sw = coarse_seq_words();
+  std::vector<uint32_t> offw((size_t)f.n_ifr * f.umax * sw, 0u);
   for (int r = 0; r < f.n_ifr; r++)
     for (int u = 0; u < f.umax; u++) {
       const int h = u < (int)uniq_of[r].size() ? uniq_of[r][u] : uniq_of[r][0];
-      for (int k4 = 0; k4 < 41; k4++) {
-        uint32_t v = 0;
-        for (int kk = 0; kk < 4; kk++)
-          v |= (uint32_t)(uint8_t)off[((size_t)r * f.cell_hyps + h) * 164 + 4 * k4 + kk] << (8 * kk);
-        offw[((size_t)r * f.umax + u) * 41 + k4] = v;
+      for (int k = 0; k < UWSPR_NSYM; k++) {
+        const uint32_t e = coarse_seq_entry(k, off[((size_t)r * f.cell_hyps + h) * 164 + k], f.off_min, f.tp);
+        if (e > 0xffffu) return fail(c, UWSPR_ERR_UNSUPPORTED, "coarse tile of %d centre columns", f.nc);
+        offw[((size_t)r * f.umax + u) * sw + k / 2] |= e << (16 * (k & 1));
       }
     }
-  // The offset sequences are read from HBM/L2 by default: 31 KB less LDS per workgroup lets other
-  // streams' kernels share the CU (+3 % under three streams); UWSPR_K3_UOFF_GLOBAL=0 stages them in LDS
-  f.uoff_global = (getenv("UWSPR_K3_UOFF_GLOBAL") && atoi(getenv("UWSPR_K3_UOFF_GLOBAL")) == 0) ? 0 : 1;
-  if (coarse_lds_bytes(f) > 160 * 1024) f.uoff_global = 1;   // keep the offset sequences out of LDS
   if (coarse_lds_bytes(f) > 160 * 1024)
     return fail(c, UWSPR_ERR_UNSUPPORTED, "coarse search needs %zu B of LDS (> 160 KiB): reduce maxdrift/cf",
                 coarse_lds_bytes(f));

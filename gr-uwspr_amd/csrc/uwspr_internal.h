@@ -84,10 +84,10 @@ struct fdr_consts {
   int band_lo, band_w;
   int cell_hyps, nlin, ntot;      // hyps per (ifr,k0) cell; linear ones; 130*cell_hyps
   int off_min, off_max, nc;       // ifd-ifr range; tile centres per row = 5 + off_max-off_min
+  int tp;                         // K3 tile row pitch in float4 (>= nc; bank-conflict padding)
   int ifr_lo, n_ifr;              // rows of the offset table
   int umax;                       // distinct offset sequences per cell (max over rows)
   int cand_slots;                 // max candidates a frame can yield
-  int uoff_global;                // K3 reads the offset sequences from HBM/L2 (LDS too small to hold them)
   float df, min_snr, min_snr_floor, threshold;
 };
 
@@ -107,7 +107,7 @@ struct uwspr_ctx {
   // constant tables in HBM
   float *d_window;     // [512]
   float *d_twiddle;    // [256][2]
-  uint32_t *d_off;     // [n_ifr][umax][41]: distinct offset sequences, 4 x int8 (ifd-ifr) per word
+  uint32_t *d_off;     // [n_ifr][umax][84]: distinct offset sequences, 2 x u16 tile byte offsets per word (k3_coarse.hip)
   uint16_t *d_umap;    // [n_ifr][cell_hyps]: hypothesis -> distinct sequence
   float *d_fe_taps;    // [1025][2] complex front-end taps (K0), built on first use
   size_t cap_audio; float *d_audio;   // staging when the audio is host memory
