@@ -48,9 +48,20 @@ constexpr int K3_THREADS = 1024;
 // rows one apart, i.e. float4 indices tp + (difference of offsets) apart: with tp = nc = 13 every
 // pair three columns apart collides (27 % of the kernel's LDS cycles); tp = 8 (mod 16) leaves only the
 // pairs eight columns apart (UWSPR_K3_PITCH=24; see coarse_tile_pitch() for why it is not the default).
-constexpr int K3_SEQ_WORDS = 84, K3_SEG_SYMS = 32;
-__host__ __device__ inline uint32_t k3_seq_entry(int k, int off, int off_min, int nc) {
-  return (uint32_t)((2 * (k % K3_SEG_SYMS)) * nc + off - off_min) * 16u;
+//
+// Three tile forms (fdr_consts::k3_mode, chosen at context creation by what fits the 160 KB of LDS):
+//   K3_TILE_F4     float4 {sqrt ps[c-3], [c-1], [c+1], [c+3]} per (row, centre c) in LDS: one
+//                  ds_read_b128 per symbol; every flowgraph-default geometry up to cf ~ 4500
+//   K3_TILE_F1     the plain sqrt row (nc + 6 floats per row) in LDS, four 4-byte gathers per symbol:
+//                  a quarter of the bytes, for search reaches up to ~ 100 columns (cf ~ 15000)
+//   K3_TILE_F1_HBM the same row image in a per-workgroup HBM/L2 scratch: any reach, slowly
+// F1 entries are ((2*(k mod 8))*tp + off - off_min) * 4 with tp = the row pitch in floats.
+constexpr int K3_SEQ_WORDS = 84;
+enum { K3_TILE_F4 = 0, K3_TILE_F1 = 1, K3_TILE_F1_HBM = 2 };
+__host__ __device__ constexpr int k3_seg_syms(int mode) { return mode == K3_TILE_F4 ? 32 : 8; }
+__host__ __device__ constexpr int k3_unit(int mode) { return mode == K3_TILE_F4 ? 16 : 4; }
+__host__ __device__ inline uint32_t k3_seq_entry(int mode, int k, int off, int off_min, int tp) {
+  return (uint32_t)((2 * (k % k3_seg_syms(mode))) * tp + off - off_min) * (uint32_t)k3_unit(mode);
 }
 typedef uint32_t k3_u4 __attribute__((ext_vector_type(4)));   // HIP's uint4 class cannot live behind an address-space pointer
 constexpr int K3_SLICE_PITCH = 68;   // floats per 64-hypothesis slice of the expanded metrics (16-B pad)
@@ -67,7 +78,7 @@ struct k3_lds_layout { size_t tile, sync, umap, total; };
 __host__ __device__ inline k3_lds_layout k3_layout(const fdr_consts &f) {
   k3_lds_layout l;
   l.tile = 0;
-  l.sync = l.tile + (size_t)f.n * f.tp * 16;
+  l.sync = l.tile + (f.k3_mode == K3_TILE_F1_HBM ? 0 : (size_t)f.n * f.tp * k3_unit(f.k3_mode));
   l.umap = l.sync + (size_t)UWSPR_NIFR * UWSPR_NK0 * f.umax * 4;
   l.total = l.umap + (((size_t)UWSPR_NIFR * f.cell_hyps * 2 + 15) & ~(size_t)15);
   // after the evaluation the tile + offset-table range is reused for the expanded
@@ -80,13 +91,21 @@ __host__ __device__ inline k3_lds_layout k3_layout(const fdr_consts &f) {
   return l;
 }
 
+template <int MODE>
 __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
     const float *__restrict__ ps, fdr_consts f, const uint32_t *__restrict__ uoff_tab,
     const uint16_t *__restrict__ umap_tab, uwspr_candidate *__restrict__ cands,
-    const int32_t *__restrict__ work, float *__restrict__ syncgrid, int grid_cap) {
+    const int32_t *__restrict__ work, float *__restrict__ syncgrid, int grid_cap,
+    float *__restrict__ tile_scratch) {
   extern __shared__ __align__(16) unsigned char smem[];
   const k3_lds_layout lay = k3_layout(f);
-  float4 *tile = reinterpret_cast<float4 *>(smem + lay.tile);        // [n][tp], nc used per row
+  constexpr int K3_SEG_SYMS = k3_seg_syms(MODE), UNIT = k3_unit(MODE);
+  // the tile: [n][tp] float4 (nc used per row) or [n][tp] floats (nc + 6 used), in LDS or in HBM
+  typedef typename std::conditional<MODE == K3_TILE_F1_HBM, const char __attribute__((address_space(1))) *,
+                                    const char *>::type tile_bytes;
+  float4 *tile = reinterpret_cast<float4 *>(smem + lay.tile);
+  float *tile1 = MODE == K3_TILE_F1_HBM ? tile_scratch + (size_t)blockIdx.x * f.n * f.tp
+                                        : reinterpret_cast<float *>(smem + lay.tile);
   float *syncbuf = reinterpret_cast<float *>(smem + lay.sync);       // [130][umax]
   uint16_t *umap = reinterpret_cast<uint16_t *>(smem + lay.umap);    // [5][cell_hyps]
 
@@ -109,11 +128,19 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   // ---- stage the sqrt tile and this candidate's offset rows ----------------
   const float *psb = ps + (size_t)b * f.n * f.band_w;
   const int c0 = if0 - 2 + f.off_min - f.band_lo;  // band column of centre index 0
-  for (int idx = tid; idx < f.n * f.nc; idx += K3_THREADS) {
-    int row = idx / f.nc, ci = idx - row * f.nc;
-    const float *pr = psb + (size_t)row * f.band_w + c0 + ci;
-    tile[row * f.tp + ci] = make_float4(ieee_sqrtf(pr[-3]), ieee_sqrtf(pr[-1]), ieee_sqrtf(pr[1]),
-                                        ieee_sqrtf(pr[3]));
+  if (MODE == K3_TILE_F4) {
+    for (int idx = tid; idx < f.n * f.nc; idx += K3_THREADS) {
+      int row = idx / f.nc, ci = idx - row * f.nc;
+      const float *pr = psb + (size_t)row * f.band_w + c0 + ci;
+      tile[row * f.tp + ci] = make_float4(ieee_sqrtf(pr[-3]), ieee_sqrtf(pr[-1]), ieee_sqrtf(pr[1]),
+                                          ieee_sqrtf(pr[3]));
+    }
+  } else {   // column q of a row = band column c0 - 3 + q: centre ci reads q = ci, ci + 2, ci + 4, ci + 6
+    const int ncw = f.nc + 6;
+    for (int idx = tid; idx < f.n * ncw; idx += K3_THREADS) {
+      int row = idx / ncw, q = idx - row * ncw;
+      tile1[row * f.tp + q] = ieee_sqrtf(psb[(size_t)row * f.band_w + c0 - 3 + q]);
+    }
   }
   // the offset sequences stay in HBM/L2 (82 KB would not leave room for the tile) and are read
   // through a GLOBAL-address-space pointer: a generic one makes them flat loads, which count on
@@ -128,7 +155,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
 #endif
 
   // ---- one lane per (cell, distinct offset sequence) -------------------------
-  const int segstep = 2 * K3_SEG_SYMS * f.tp * 16;
+  const int segstep = 2 * K3_SEG_SYMS * f.tp * UNIT;
   const int neval = UWSPR_NIFR * UWSPR_NK0 * f.umax;
   for (int g = tid; g < neval; g += K3_THREADS) {
     const int cell = g / f.umax, u = g - cell * f.umax;
@@ -136,16 +163,24 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
     // the sequence as 16-bit BYTE offsets into the tile, relative to the (row k0, this cell's
     // centre) float4 of the current 32-symbol segment (k3_seq_entry): a gather address is one add
     const seq_ptr ot = uo_base + (ifr_i * f.umax + u) * (K3_SEQ_WORDS / 4);
-    const char *tb = reinterpret_cast<const char *>(tile) + (k0 * f.tp + ifr_i) * 16;
+    tile_bytes tb = (MODE == K3_TILE_F4 ? (tile_bytes)reinterpret_cast<const char *>(tile)
+                                        : (tile_bytes)(uintptr_t)tile1) + (k0 * f.tp + ifr_i) * UNIT;
     float ss = 0.0f, pw = 0.0f;
     // Software pipeline over groups of 4 symbols: the 4 gathers of the next group are in flight
     // while this one is accumulated, and the offset words (16 B = 8 symbols per load) are
     // requested two loads ahead of their use: neither the LDS nor the L2 latency is exposed.
     float4 Pa[4], Pb[4];
     k3_u4 wa = ot[0], wb = ot[1], wc = ot[2];
+    auto gather1 = [&](uint32_t e) -> float4 {
+      if (MODE == K3_TILE_F4) return *reinterpret_cast<const float4 *>((const char *)tb + e);
+      typedef typename std::conditional<MODE == K3_TILE_F1_HBM, const float __attribute__((address_space(1))) *,
+                                        const float *>::type fp;
+      const fp q = (fp)(tb + e);
+      return make_float4(q[0], q[2], q[4], q[6]);
+    };
     auto gather2 = [&](float4 *P, uint32_t w) {
-      P[0] = *reinterpret_cast<const float4 *>(tb + (w & 0xffffu));
-      P[1] = *reinterpret_cast<const float4 *>(tb + (w >> 16));
+      P[0] = gather1(w & 0xffffu);
+      P[1] = gather1(w >> 16);
     };
     auto accumulate = [&](const float4 *P, int k, int count) {
 #pragma unroll
@@ -327,24 +362,45 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
 
 size_t coarse_lds_bytes(const fdr_consts &f) { return k3_layout(f).total; }
 int coarse_seq_words() { return K3_SEQ_WORDS; }
-int coarse_tile_pitch(fdr_consts f) {
+// Picks the tile form and its row pitch (f.k3_mode, f.tp); returns the floats of HBM scratch one
+// workgroup needs (0 unless the tile lives in HBM).
+size_t coarse_plan(fdr_consts &f) {
   // measured: pitch 24 instead of 13 made the kernel 3 % faster for 61 KB more LDS (the conflicts
   // are not what bounds the gather loop) -- the compact tile stays the default
   int want = f.nc;
   if (const char *e = getenv("UWSPR_K3_PITCH")) { if (atoi(e) >= f.nc) want = atoi(e); }
-  f.tp = want;
-  return k3_layout(f).total <= 160 * 1024 ? want : f.nc;
+  int force = -1;
+  if (const char *e = getenv("UWSPR_K3_TILE")) force = atoi(e);   // tests: 0 / 1 / 2
+  f.k3_mode = K3_TILE_F4;
+  if (force <= K3_TILE_F4) {
+    f.tp = want;
+    if (k3_layout(f).total <= 160 * 1024) return 0;
+    f.tp = f.nc;
+    if (k3_layout(f).total <= 160 * 1024) return 0;
+  }
+  f.tp = f.nc + 6;
+  f.k3_mode = K3_TILE_F1;
+  if (force <= K3_TILE_F1 && k3_layout(f).total <= 160 * 1024) return 0;
+  f.k3_mode = K3_TILE_F1_HBM;
+  return (size_t)f.n * f.tp;
 }
-uint32_t coarse_seq_entry(int k, int off, int off_min, int nc) { return k3_seq_entry(k, off, off_min, nc); }
+uint32_t coarse_seq_entry(const fdr_consts &f, int k, int off) {
+  return k3_seq_entry(f.k3_mode, k, off, f.off_min, f.tp);
+}
 
 void launch_coarse(uwspr_ctx *c, int B) {
   const fdr_consts &f = c->fc;
   prof_scope ps(c, UWSPR_K_COARSE, (int64_t)B);
   const long long items_max = (long long)f.cand_slots * B;
   const int grid = (int)std::min<long long>(items_max, c->num_cus);
-  hipLaunchKernelGGL(k3_coarse, dim3(grid), dim3(K3_THREADS), coarse_lds_bytes(f), c->stream,
-                     c->d_ps, f, c->d_off, c->d_umap, c->cur_cands, c->d_work, c->d_syncgrid,
-                     c->d_syncgrid ? c->grid_cap : 0);
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(K3_THREADS), coarse_lds_bytes(f), c->stream,
+                       c->d_ps, f, c->d_off, c->d_umap, c->cur_cands, c->d_work, c->d_syncgrid,
+                       c->d_syncgrid ? c->grid_cap : 0, c->d_k3_tile);
+  };
+  if (f.k3_mode == K3_TILE_F4) go(k3_coarse<K3_TILE_F4>);
+  else if (f.k3_mode == K3_TILE_F1) go(k3_coarse<K3_TILE_F1>);
+  else go(k3_coarse<K3_TILE_F1_HBM>);
 }
 
 int coarse_configure(const fdr_consts &f) {
@@ -352,9 +408,12 @@ int coarse_configure(const fdr_consts &f) {
   if (need > 160 * 1024) return -1;
   // the attribute belongs to the function, not to a context: always the device maximum, so that a
   // second context with a smaller tile cannot lower the limit under an earlier one
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k3_coarse),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  return e == hipSuccess ? 0 : -2;
+  const void *fn[3] = {reinterpret_cast<const void *>(k3_coarse<K3_TILE_F4>),
+                       reinterpret_cast<const void *>(k3_coarse<K3_TILE_F1>),
+                       reinterpret_cast<const void *>(k3_coarse<K3_TILE_F1_HBM>)};
+  for (const void *p : fn)
+    if (hipFuncSetAttribute(p, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -2;
+  return 0;
 }
 
 }  // namespace uwspr

@@ -17,8 +17,8 @@ namespace uwspr {
 int coarse_configure(const fdr_consts &f);
 size_t coarse_lds_bytes(const fdr_consts &f);
 int coarse_seq_words();
-int coarse_tile_pitch(fdr_consts f);
-uint32_t coarse_seq_entry(int k, int off, int off_min, int nc);
+size_t coarse_plan(fdr_consts &f);
+uint32_t coarse_seq_entry(const fdr_consts &f, int k, int off);
 }  // namespace uwspr
 
 using namespace uwspr;
@@ -93,7 +93,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->p = *p;
   c->device = device;
   c->own_stream = c->stream = nullptr;
-  c->d_window = c->d_twiddle = nullptr; c->d_off = nullptr; c->d_umap = nullptr;
+  c->d_window = c->d_twiddle = nullptr; c->d_off = nullptr; c->d_umap = nullptr; c->d_k3_tile = nullptr;
   c->d_fe_taps = nullptr; c->cap_audio = 0; c->d_audio = nullptr;
   c->cap_frames_bytes = 0; c->d_frames = nullptr; c->cap_B = 0;
   c->d_ps = c->d_psavg = c->d_smraw = c->d_smspec = c->d_noise = nullptr;
@@ -241,14 +241,14 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   }
   // [ifr][u][84] words of 2 x u16 tile byte offsets (coarse_seq_entry); rows with fewer distinct
   // sequences repeat sequence 0
-  f.tp = coarse_tile_pitch(f);
+  const size_t k3_scratch = coarse_plan(f);   // tile form + pitch (k3_coarse.hip)
   const int sw = coarse_seq_words();
   std::vector<uint32_t> offw((size_t)f.n_ifr * f.umax * sw, 0u);
   for (int r = 0; r < f.n_ifr; r++)
     for (int u = 0; u < f.umax; u++) {
       const int h = u < (int)uniq_of[r].size() ? uniq_of[r][u] : uniq_of[r][0];
       for (int k = 0; k < UWSPR_NSYM; k++) {
-        const uint32_t e = coarse_seq_entry(k, off[((size_t)r * f.cell_hyps + h) * 164 + k], f.off_min, f.tp);
+        const uint32_t e = coarse_seq_entry(f, k, off[((size_t)r * f.cell_hyps + h) * 164 + k]);
         if (e > 0xffffu) return fail(c, UWSPR_ERR_UNSUPPORTED, "coarse tile of %d centre columns", f.nc);
         offw[((size_t)r * f.umax + u) * sw + k / 2] |= e << (16 * (k & 1));
       }
@@ -256,6 +256,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   if (coarse_lds_bytes(f) > 160 * 1024)
     return fail(c, UWSPR_ERR_UNSUPPORTED, "coarse search needs %zu B of LDS (> 160 KiB): reduce maxdrift/cf",
                 coarse_lds_bytes(f));
+  if (k3_scratch) HIPCHK(c, hipMalloc((void **)&c->d_k3_tile, k3_scratch * sizeof(float) * (size_t)c->num_cus));
   HIPCHK(c, hipMalloc((void **)&c->d_umap, umap.size() * sizeof(uint16_t)));
   HIPCHK(c, hipMemcpy(c->d_umap, umap.data(), umap.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
   HIPCHK(c, hipMalloc((void **)&c->d_window, size * sizeof(float)));
@@ -271,7 +272,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
 extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   if (!c) return;
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
-  void *bufs[] = {c->d_window, c->d_twiddle, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
+  void *bufs[] = {c->d_window, c->d_twiddle, c->d_k3_tile, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
                   c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_cent,
                   c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter, c->d_sched_stamps, c->d_pwin, c->d_need, c->d_stream[0], c->d_stream[1], c->d_stream_frames, c->d_tmpc, c->d_tmpn};
   for (void *b : bufs) if (b) (void)hipFree(b);

@@ -84,7 +84,8 @@ struct fdr_consts {
   int band_lo, band_w;
   int cell_hyps, nlin, ntot;      // hyps per (ifr,k0) cell; linear ones; 130*cell_hyps
   int off_min, off_max, nc;       // ifd-ifr range; tile centres per row = 5 + off_max-off_min
-  int tp;                         // K3 tile row pitch in float4 (>= nc; bank-conflict padding)
+  int tp;                         // K3 tile row pitch, in float4 (tile form 0) or floats (forms 1, 2)
+  int k3_mode;                    // K3 tile form (k3_coarse.hip: K3_TILE_*)
   int ifr_lo, n_ifr;              // rows of the offset table
   int umax;                       // distinct offset sequences per cell (max over rows)
   int cand_slots;                 // max candidates a frame can yield
@@ -107,6 +108,7 @@ struct uwspr_ctx {
   // constant tables in HBM
   float *d_window;     // [512]
   float *d_twiddle;    // [256][2]
+  float *d_k3_tile;    // [num_cus][n][tp] sqrt rows when the coarse tile does not fit LDS (K3_TILE_F1_HBM), else null
   uint32_t *d_off;     // [n_ifr][umax][84]: distinct offset sequences, 2 x u16 tile byte offsets per word (k3_coarse.hip)
   uint16_t *d_umap;    // [n_ifr][cell_hyps]: hypothesis -> distinct sequence
   float *d_fe_taps;    // [1025][2] complex front-end taps (K0), built on first use

@@ -527,16 +527,18 @@ def test_schedule_on_a_silent_frame(ctx, G, oracle):
 
 def test_other_carrier_and_frame_parameters(G, oracle):
     """Parameters away from the flowgraph defaults: cf = 2000 and 3000 (the SLM Doppler reach,
-    hence the coarse tile width, scales with cf; at 3000 the offset sequences no longer fit
-    LDS beside the tile and are read from HBM/L2), a wide band with few candidates kept
-    (maxfreqs = 3), cf = 500.  Candidates and the whole schedule against the oracle.
-    A tile beyond the 160 KB of LDS altogether is a status code, not a crash."""
+    hence the coarse tile width, scales with cf), a wide band with few candidates kept
+    (maxfreqs = 3), cf = 500, and carriers whose tile no longer fits LDS as float4 per centre:
+    cf = 6000 (plain sqrt rows in LDS, four gathers per symbol) and cf = 24000 (reach +-64 bins:
+    the rows live in an HBM scratch).  Candidates and the whole schedule against the oracle.
+    A geometry the build does not implement is a status code, not a crash."""
     with pytest.raises(G.UwsprError) as ei:
-        G.Context(cf=6000, halfbandwidth=20)
-    assert ei.value.status == -3 and "LDS" in str(ei.value)   # UWSPR_ERR_UNSUPPORTED
+        G.Context(spb=128)
+    assert ei.value.status == -3   # UWSPR_ERR_UNSUPPORTED
     frames = G.synth.make_frames(3, seed=271828, snr_db=-16.0, halfbandwidth=20)
     for kw in ({"cf": 2000, "halfbandwidth": 20}, {"cf": 3000, "halfbandwidth": 20},
-               {"halfbandwidth": 30, "maxfreqs": 3, "maxdrift": 1}, {"cf": 500, "halfbandwidth": 12}):
+               {"halfbandwidth": 30, "maxfreqs": 3, "maxdrift": 1}, {"cf": 500, "halfbandwidth": 12},
+               {"cf": 6000, "halfbandwidth": 20}, {"cf": 24000, "halfbandwidth": 20}):
         c = G.Context(**kw)
         try:
             cands, out = c.pipeline_batch(frames, max_per_frame=2)
@@ -559,12 +561,14 @@ def test_other_carrier_and_frame_parameters(G, oracle):
                         assert (o["symbols"] == d["symbols"]).all(), (kw, b, j)
 
 
-def test_coarse_search_offset_table_in_lds_or_hbm(G, frames, monkeypatch):
-    """K3 reads the deduplicated offset sequences from HBM/L2 by default and from an LDS
-    copy with UWSPR_K3_UOFF_GLOBAL=0: identical candidates and identical 16 380 metrics."""
+def test_coarse_search_tile_forms_agree(G, frames, monkeypatch):
+    """K3's three tile forms (float4 per centre in LDS -- the default --, plain sqrt rows in LDS,
+    sqrt rows in HBM: UWSPR_K3_TILE = 0 / 1 / 2) and a padded row pitch (UWSPR_K3_PITCH): identical
+    candidates and identical 16 380 metrics per candidate."""
     res = []
-    for v in ("1", "0"):
-        monkeypatch.setenv("UWSPR_K3_UOFF_GLOBAL", v)
+    for name, v in (("UWSPR_K3_TILE", "0"), ("UWSPR_K3_TILE", "1"), ("UWSPR_K3_TILE", "2"), ("UWSPR_K3_PITCH", "24")):
+        monkeypatch.delenv("UWSPR_K3_TILE", raising=False)
+        monkeypatch.setenv(name, v)
         c = G.Context()
         try:
             c.keep_syncgrid(2)
@@ -573,18 +577,19 @@ def test_coarse_search_offset_table_in_lds_or_hbm(G, frames, monkeypatch):
         finally:
             c.close()
         res.append((cands, grid))
-    (ca, ga), (cb, gb) = res
-    for b in range(len(frames)):
-        assert len(ca[b]) == len(cb[b]) >= 1
-        for j, (x, y) in enumerate(zip(ca[b], cb[b])):
-            for k in ("m_type", "freq", "snr", "sync", "shift"):
-                assert x[k].tobytes() == y[k].tobytes(), (b, j, k)
-            if int(x["m_type"]) == 1:
-                assert all(x[k] == y[k] for k in ("V1", "V2", "p1", "p2"))
-            else:
-                assert x.tobytes()[24:28] == y.tobytes()[24:28]
-            if j < 2:
-                assert ga[b, j].tobytes() == gb[b, j].tobytes()
+    ca, ga = res[0]
+    for cb, gb in res[1:]:
+        for b in range(len(frames)):
+            assert len(ca[b]) == len(cb[b]) >= 1
+            for j, (x, y) in enumerate(zip(ca[b], cb[b])):
+                for k in ("m_type", "freq", "snr", "sync", "shift"):
+                    assert x[k].tobytes() == y[k].tobytes(), (b, j, k)
+                if int(x["m_type"]) == 1:
+                    assert all(x[k] == y[k] for k in ("V1", "V2", "p1", "p2"))
+                else:
+                    assert x.tobytes()[24:28] == y.tobytes()[24:28]
+                if j < 2:
+                    assert ga[b, j].tobytes() == gb[b, j].tobytes()
 
 
 def test_lazy_tries_and_resume_equal_the_eager_schedule(G, frames, vec):
