@@ -15,8 +15,8 @@
 //   pass A (h=1,2,4):    lane L holds p = 8*rev6(L) + r,      r = 0..7
 //   pass B (h=8,16,32):  lane L holds p = 64*(L>>3) + 8*b + (L&7), b = 0..7
 //   pass C (h=64..256):  lane L holds p = 64*a + L,           a = 0..7
-// Functions are host+device so the lane algebra can be unit-tested by
-// emulating the 64 lanes on the CPU (tests/host_emul).
+// Functions are host+device so the lane algebra is unit-tested by emulating
+// the 64 lanes on the CPU (tests/host/fft_lane_emul.cc, tests/test_host_blocks.py).
 #pragma once
 
 #ifdef __HIPCC__
@@ -107,6 +107,33 @@ UWSPR_HD void pass_bc(cpx v[8], const pass_tw &t) {
   }
 #pragma unroll
   for (int e = 0; e < 4; e++) bfly(v[e], v[e + 4], t.s3[e].r, t.s3[e].i);
+}
+
+// Pass C when only bins 0..63 and 448..511 are wanted (slots 0 and 7: a pass band within 64 columns of
+// the centre, which every shipped flowgraph has).  The wanted outputs are computed by exactly the
+// butterflies of pass_bc -- same operands, same operations -- and the others are left out: the
+// first fused stage in full, then one output of each second-stage butterfly (slots 0, 4 from the
+// sums, 3, 7 from the differences) and one output of two third-stage butterflies.  88 operations
+// instead of 120.  Slots 1..6 of v are undefined afterwards.
+UWSPR_HD void bfly_sum(cpx &u, const cpx &v, float wr, float wi) {   // u <- u + w*v
+  float tr = wr * v.r - wi * v.i;
+  float ti = wr * v.i + wi * v.r;
+  u.r = u.r + tr; u.i = u.i + ti;
+}
+UWSPR_HD void bfly_diff(const cpx &u, cpx &v, float wr, float wi) {  // v <- u - w*v
+  float tr = wr * v.r - wi * v.i;
+  float ti = wr * v.i + wi * v.r;
+  v.r = u.r - tr; v.i = u.i - ti;
+}
+UWSPR_HD void pass_c_narrow(cpx v[8], const pass_tw &t) {
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) bfly(v[e], v[e + 1], t.s1.r, t.s1.i);
+  bfly_sum(v[0], v[2], t.s2[0].r, t.s2[0].i);
+  bfly_sum(v[4], v[6], t.s2[0].r, t.s2[0].i);
+  bfly_diff(v[1], v[3], t.s2[1].r, t.s2[1].i);
+  bfly_diff(v[5], v[7], t.s2[1].r, t.s2[1].i);
+  bfly_sum(v[0], v[4], t.s3[0].r, t.s3[0].i);
+  bfly_diff(v[3], v[7], t.s3[3].r, t.s3[3].i);
 }
 
 // Which input sample (0..511) lane L keeps in register slot r before pass A:

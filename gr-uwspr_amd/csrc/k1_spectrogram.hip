@@ -18,6 +18,8 @@
 #include "uwspr_internal.h"
 #include "fft512_lane.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 
 #pragma clang fp contract(off)
@@ -56,6 +58,9 @@ __device__ unsigned long long k1_stamp_buf[3 * 16384];
 #define K1_STAMP(slot)
 #endif
 
+// NARROW: the band lies within columns 192..319 (bins 0..63 and 448..511): pass C computes only
+// register slots 0 and 7 (fft512_lane.h: pass_c_narrow), 9 % of the kernel's arithmetic less.
+template <bool NARROW>
 __global__ __launch_bounds__(64 * K1_WAVES, 3) void k1_spectrogram(
     const float2 *__restrict__ frames, int B, int rpw, int fl, int n, const float *__restrict__ window,
     const float2 *__restrict__ twiddle, float *__restrict__ ps, int band_lo, int band_w,
@@ -129,11 +134,12 @@ __global__ __launch_bounds__(64 * K1_WAVES, 3) void k1_spectrogram(
     k1_wave_fence();
 #pragma unroll
     for (int e = 0; e < 8; e++) y[e] = lds[laneC ^ k1_slotC(e)];
-    pass_bc(y, twC);
+    if (NARROW) pass_c_narrow(y, twC); else pass_bc(y, twC);
     k1_landed(raw[(2 * ph) & 7]); k1_landed(raw[(2 * ph + 1) & 7]);
     float *out = ps + ((size_t)b * n + row) * band_w;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
+      if (NARROW && e != 0 && e != 7) continue;
       int col = out_col(L, e) - band_lo;
       // FDR_impl.cc:252: re*re + im*im, two products, one add, no fusion
       if (col >= 0 && col < band_w) out[col] = y[e].r * y[e].r + y[e].i * y[e].i;
@@ -158,12 +164,17 @@ extern "C" int uwspr_debug_k1_stamps(unsigned long long *out, int nwaves) {
 void launch_spectrogram(uwspr_ctx *c, const float *frames, int B) {
   const fdr_consts &f = c->fc;
   prof_scope ps(c, UWSPR_K_SPECTROGRAM, B);
-  const int rpw = B >= K1_LARGE_BATCH ? K1_ROWS_LARGE : K1_ROWS_SMALL;
+  int rpw = B >= K1_LARGE_BATCH ? K1_ROWS_LARGE : K1_ROWS_SMALL;
+  if (const char *e = getenv("UWSPR_K1_ROWS")) { if (atoi(e) > 0) rpw = atoi(e); }   // A/B only
   const int items = B * ((f.n + rpw - 1) / rpw);
   dim3 grid((items + K1_WAVES - 1) / K1_WAVES);
-  hipLaunchKernelGGL(k1_spectrogram, grid, dim3(64 * K1_WAVES), 0, c->stream,
-                     (const float2 *)frames, B, rpw, f.fl, f.n, c->d_window,
-                     (const float2 *)c->d_twiddle, c->d_ps, f.band_lo, f.band_w, c->d_work);
+  const bool narrow = f.band_lo >= 192 && f.band_lo + f.band_w <= 320;
+  auto go = [&](auto kern) {
+    hipLaunchKernelGGL(kern, grid, dim3(64 * K1_WAVES), 0, c->stream,
+                       (const float2 *)frames, B, rpw, f.fl, f.n, c->d_window,
+                       (const float2 *)c->d_twiddle, c->d_ps, f.band_lo, f.band_w, c->d_work);
+  };
+  if (narrow) go(k1_spectrogram<true>); else go(k1_spectrogram<false>);
 }
 
 }  // namespace uwspr

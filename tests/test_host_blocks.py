@@ -25,6 +25,18 @@ def exe(G):
     return EXE
 
 
+def test_fft_lane_algebra_is_the_radix2_dit_bit_for_bit(tmp_path):
+    """K1's transform (fft512_lane.h) emulated lane by lane on the CPU: three register passes and the
+    two swizzled exchanges reproduce the textbook radix-2 DIT bit for bit, the narrow pass C its
+    slots 0 and 7, and the exchange image is a conflict-free permutation."""
+    exe_ = str(tmp_path / "fft_lane_emul")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-ffp-contract=off",
+                    "-I" + os.path.join(ROOT, "gr-uwspr_amd", "csrc"),
+                    os.path.join(ROOT, "tests", "host", "fft_lane_emul.cc"), "-o", exe_], check=True)
+    r = subprocess.run([exe_], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "OK", r.stdout + r.stderr
+
+
 def test_public_headers_keep_the_reference_signatures():
     h = os.path.join(ROOT, "gr-uwspr_amd", "host", "uwspr")
     fdr = open(os.path.join(h, "FDR.h")).read()
