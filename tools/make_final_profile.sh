@@ -29,4 +29,15 @@ grep "^{" $P/bench_plain.log > ${O}_bench.json
 for form in fused staged; do cp $(ls $P/trace_$form/*/*kernel_stats.csv | head -1) ${O}_kernel_stats_${form}_streams1.csv; done
 cp $(ls $P/trace_default/*/*kernel_stats.csv | head -1) ${O}_kernel_stats.csv
 python3 tools/make_traffic.py $P ${O}_rocprof_summary.txt
+# the bench line was printed before this run's PMC passes were condensed: give it this run's figures
+python3 - ${O}_bench.json <<'PY'
+import json, sys
+b = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])
+t = json.load(open("profiles/k4_traffic.json"))
+form = "fused" if "fused" in b["config"].get("sched", "") else "staged"
+b["roofline"]["traffic"] = t[form]["bytes_per_step"]
+b["roofline"]["valu_issue_utilisation_pmc"] = t[form]["valu_issue_utilisation"]
+b["roofline"]["traffic_source"] = t[form]["source"]
+open(sys.argv[1], "w").write(json.dumps(b) + "\n")
+PY
 wc -l ${O}_rocprof_summary.txt
