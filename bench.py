@@ -187,11 +187,22 @@ def main():
                for k in range(nb)]
     K = args.steps
 
+    # The HIP streams are created (and used) ONCE, before any context: a stream created after other
+    # streams were destroyed (every closed context destroys its own) can end up sharing a hardware
+    # queue with another lane -- the same three-lane configuration then measured 12 % slower
+    # (tools/stream_probe.py).  Trials and the timed run use these same streams.
+    max_lanes = 3 if args.streams <= 0 else args.streams
+    lane_streams = [torch.cuda.Stream(device=dev) for _ in range(max_lanes)]
+    for st in lane_streams:
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=dev)
+    torch.cuda.synchronize()
+
     def make_lanes(ns, fused):
         os.environ["UWSPR_SCHED_FUSED"] = "1" if fused else "0"
         lanes = []
-        for _ in range(ns):
-            st = torch.cuda.Stream(device=dev)
+        for k in range(ns):
+            st = lane_streams[k]
             cx = G.Context(device=local)
             cx.set_stream(st.cuda_stream)
             lanes.append({"stream": st, "ctx": cx,
