@@ -1008,7 +1008,6 @@ __global__ __launch_bounds__(64 * K4GR_WAVES) void k4_grid(
     sd = (float)sn;
   }
 
-  const float2 *mywin = win + (i - i_first) * ga.wstride;
   float c = 1.0f, s = 0.0f;
   float inp[NL], quad[NL];
 #pragma unroll
