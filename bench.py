@@ -335,22 +335,23 @@ def main():
         torch.cuda.synchronize()
         lazy_by_lanes = {}
         lz = None
-        for nl in range(1, max_lanes + 1):      # 1, 2, 3 batches in flight; the last set stays open for the resume leg
-            if lz is not None:
-                close_lanes(lz)
-            lz = make_lanes(nl, True)
-            for ln in lz:
-                ln["ctx"].set_tries(1)
-            for i in range(6):
-                step(lz, i)
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            for i in range(K):
-                step(lz, i)
-            torch.cuda.synchronize()
-            lazy_by_lanes[nl] = time.perf_counter() - t2
-        nbest = min(lazy_by_lanes, key=lazy_by_lanes.get)
-        dl = lazy_by_lanes[nbest]
+        for lf in (False, True):                    # both schedule forms ...
+            for nl in range(1, max_lanes + 1):      # ... with 1, 2, 3 batches in flight
+                if lz is not None:
+                    close_lanes(lz)
+                lz = make_lanes(nl, lf)
+                for ln in lz:
+                    ln["ctx"].set_tries(1)
+                for i in range(6):
+                    step(lz, i)
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
+                for i in range(K):
+                    step(lz, i)
+                torch.cuda.synchronize()
+                lazy_by_lanes[(lf, nl)] = time.perf_counter() - t2
+        (lbest_fused, nbest) = min(lazy_by_lanes, key=lazy_by_lanes.get)
+        dl = lazy_by_lanes[(lbest_fused, nbest)]
         lz[0]["ctx"].pipeline_batch_into(batches[0], lz[0]["cands"], lz[0]["npk"], lz[0]["out"], max_per_frame=1)
         torch.cuda.synchronize()
         out1 = np.frombuffer(lz[0]["out"].cpu().numpy().tobytes(), N.DEMOD_DTYPE).reshape(B, 1)
@@ -362,10 +363,12 @@ def main():
         torch.cuda.synchronize()
         t_res = time.perf_counter() - t3
         lazy = {"frames_per_s": B * K / dl, "ms_per_step": 1e3 * dl / K, "tries": 1, "streams": nbest,
-                "ms_per_step_by_streams": {str(k): 1e3 * v / K for k, v in lazy_by_lanes.items()},
+                "sched": "fused" if lbest_fused else "staged",
+                "ms_per_step_by_form_and_streams": {("%s x%d" % ("fused" if f else "staged", k)): 1e3 * v / K
+                                                    for (f, k), v in lazy_by_lanes.items()},
                 "decoded_by_try_0": int(ok1.sum()), "of": int(B), "resume_ms_for_the_rest": 1e3 * t_res,
-                "note": "fused form with uwspr_set_tries(1), this rank: the reference stops at its first decoding "
-                        "try (cc:457-490); the rest is produced on demand by uwspr_demod_resume"}
+                "note": "uwspr_set_tries(1), this rank: the reference stops at its first decoding try "
+                        "(cc:457-490); the rest is produced on demand by uwspr_demod_resume"}
         close_lanes(lz)
         os.environ["UWSPR_SCHED_FUSED"] = "1" if fused else "0"
     if world > 1:

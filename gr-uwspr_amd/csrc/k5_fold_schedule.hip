@@ -336,7 +336,8 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
                                                 dev_hyp *__restrict__ hout,
                                                 dev_grp *__restrict__ grps,
                                                 uwspr_candidate *__restrict__ cent,
-                                                int32_t *__restrict__ cframe, bool reuse, int team = 0) {
+                                                int32_t *__restrict__ cframe, bool reuse, int team = 0,
+                                                int njig = UWSPR_NJIG) {
   // team (stage 5 only): lanes 0..19 of the first wavefront all derive the same new state, in
   // lockstep, and share the emission -- lane t < 17 writes try t, lanes 17..19 the lag groups
   cand_state st = state[slot];
@@ -345,7 +346,8 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
   constexpr int NOUT = STAGE == 1 ? 5 : STAGE == 2 ? 2 : STAGE == 3 ? 5 : STAGE == 4 ? 5 : 17;
   const dev_hyp *hi = hin + (size_t)slot * NIN;
   const float *sy = sync_of_slot;
-  dev_hyp *ho = hout + (size_t)slot * NOUT;
+  // stage 5 with lazy tries (njig < 17): only tries idt < njig, packed njig per slot, no lag groups
+  dev_hyp *ho = hout + (size_t)slot * (STAGE == 5 ? njig : NOUT);
 
   if (STAGE == 1) {
     // after S0 (mode 0) -> S1 (cc:416-419): mode 1, f = f1 + ifreq*0.25, lag = shift1
@@ -402,7 +404,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
   } else {
     // after S4 -> S5 (cc:457-468): 17 jiggered shifts, mode 2
     if (st.worth) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
-    if (team < UWSPR_NJIG) {
+    if (team < njig) {
       const int idt = team;
       int ii = (idt + 1) / 2;
       if (idt % 2 == 1) ii = -ii;
@@ -425,7 +427,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
       }
       uint32_t hmap = 0;
       for (int l = 0; l < n; l++) hmap |= (uint32_t)(id[l] - idt0) << (4 * l);
-      emit_group(&grps[slot * 3 + g], st, st.worth != 0, st.f1, st.drift1,
+      emit_group(&grps[slot * 3 + g], st, st.worth != 0 && njig >= UWSPR_NJIG, st.f1, st.drift1,
                  slot * UWSPR_NJIG + idt0, gl, n, hmap);
     }
   }
@@ -439,7 +441,7 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
                              const float4 *__restrict__ p, float *__restrict__ sync,
                              dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
                              uwspr_candidate *__restrict__ cent, int32_t *__restrict__ cframe, int nslots,
-                             int reuse) {
+                             int reuse, int njig) {
   constexpr int NIN = STAGE == 3 ? 2 : 5;
   __shared__ k5_wave_lds L[NIN];
   __shared__ float sy[NIN];
@@ -453,7 +455,7 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
   __syncthreads();
   if (STAGE == 5) {
     if (threadIdx.x < UWSPR_NJIG + 3)
-      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x);
+      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x, njig);
   } else if (threadIdx.x == 0) {
     sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0);
   }
@@ -463,7 +465,7 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
 __global__ void k_sched_finish(const cand_state *__restrict__ state,
                                const dev_hyp *__restrict__ h5, const float *__restrict__ sync5,
                                const uint8_t *__restrict__ sym5, uwspr_demod_out *__restrict__ out,
-                               int nslots) {
+                               int nslots, int njig) {
   const int slot = blockIdx.x;
   if (slot >= nslots) return;
   const cand_state st = state[slot];
@@ -474,10 +476,13 @@ __global__ void k_sched_finish(const cand_state *__restrict__ state,
     o->worth_a_try = st.worth; o->_pad[0] = 0; o->_pad[1] = 0;
   }
   const bool on = st.frame >= 0 && st.worth;
+  // lazy tries: the njig produced tries are packed njig per slot; the others read as zero (cc:457-490
+  // would not have produced them either unless the earlier ones failed to decode)
   if (tid < UWSPR_NJIG) {
-    const size_t q = (size_t)slot * UWSPR_NJIG + tid;
+    const bool have = on && tid < njig;
+    const size_t q = (size_t)slot * njig + tid;
     float rms = 0.0f;
-    if (on) {
+    if (have) {
       float sq = 0.0f;
       for (int i = 0; i < UWSPR_NSYM; i++) {
         const float y = (float)((double)(float)sym5[q * UWSPR_NSYM + i] - 128.0);  // cc:471
@@ -485,12 +490,12 @@ __global__ void k_sched_finish(const cand_state *__restrict__ state,
       }
       rms = (float)sqrt((double)sq / 162.0);  // cc:474
     }
-    o->jig_sync[tid] = on ? sync5[q] : 0.0f;
+    o->jig_sync[tid] = have ? sync5[q] : 0.0f;
     o->jig_rms[tid] = rms;
-    o->jig_shift[tid] = on ? h5[q].lag : 0;
+    o->jig_shift[tid] = have ? h5[q].lag : 0;
   }
   for (int e = tid; e < UWSPR_NJIG * UWSPR_NSYM; e += blockDim.x)
-    (&o->symbols[0][0])[e] = on ? sym5[(size_t)slot * UWSPR_NJIG * UWSPR_NSYM + e] : (uint8_t)0;
+    (&o->symbols[0][0])[e] = (on && e < njig * UWSPR_NSYM) ? sym5[(size_t)slot * njig * UWSPR_NSYM + e] : (uint8_t)0;
 }
 
 // Per-frame slab for the multi-GPU gather: {npk, pad[3]} | candidate_t[K] |
@@ -533,27 +538,27 @@ void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t
 
 // hyps of consecutive stages ping-pong between the two halves of d_hyps;
 // stage s consumes the tone magnitudes K4 just wrote for the hypotheses of stage s-1
-void launch_fold_step(uwspr_ctx *c, int stage, int nslots) {
+void launch_fold_step(uwspr_ctx *c, int stage, int nslots, int njig) {
   prof_scope ps(c, UWSPR_K_FOLD, (int64_t)nslots * (stage == 3 ? 2 : 5));
   dev_hyp *half0 = c->d_hyps, *half1 = c->d_hyps + (size_t)nslots * UWSPR_NJIG;
   dev_hyp *hin = (stage & 1) ? half0 : half1;
   dev_hyp *hout = (stage & 1) ? half1 : half0;
   dim3 g(nslots);
   switch (stage) {
-    case 1: hipLaunchKernelGGL(k5_fold_step<1>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0); break;
-    case 2: hipLaunchKernelGGL(k5_fold_step<2>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0); break;
-    case 3: hipLaunchKernelGGL(k5_fold_step<3>, g, dim3(128), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0); break;
-    case 4: hipLaunchKernelGGL(k5_fold_step<4>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0); break;
-    default: hipLaunchKernelGGL(k5_fold_step<5>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0); break;
+    case 1: hipLaunchKernelGGL(k5_fold_step<1>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0, njig); break;
+    case 2: hipLaunchKernelGGL(k5_fold_step<2>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0, njig); break;
+    case 3: hipLaunchKernelGGL(k5_fold_step<3>, g, dim3(128), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0, njig); break;
+    case 4: hipLaunchKernelGGL(k5_fold_step<4>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0, njig); break;
+    default: hipLaunchKernelGGL(k5_fold_step<5>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0, njig); break;
   }
 }
 
-void launch_sched_finish(uwspr_ctx *c, int nslots) {
+void launch_sched_finish(uwspr_ctx *c, int nslots, int njig) {
   prof_scope ps(c, UWSPR_K_SCHED, nslots);
   // stage-5 hyps live in the half selected by (5 & 1) -> half1
   dev_hyp *h5 = c->d_hyps + (size_t)nslots * UWSPR_NJIG;
   hipLaunchKernelGGL(k_sched_finish, dim3(nslots), dim3(256), 0, c->stream, c->d_state, h5,
-                     c->d_sync, c->d_sym, c->cur_dout, nslots);
+                     c->d_sync, c->d_sym, c->cur_dout, nslots, njig);
 }
 
 }  // namespace uwspr

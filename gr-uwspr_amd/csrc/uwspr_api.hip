@@ -687,13 +687,14 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
   const size_t nslots = (size_t)B * per_frame;
   int rc;
   if ((rc = ensure(c, &c->d_state, &c->cap_state, nslots))) return rc;
-  if (!c->use_fused && c->ntries < UWSPR_NJIG)
-    return fail(c, UWSPR_ERR_UNSUPPORTED, "lazy tries (uwspr_set_tries) need the fused schedule kernel (UWSPR_SCHED_FUSED=1)");
-  if (c->use_fused) {
-    // k6_sched: one workgroup per candidate, S0..S5 back to back
+  const int njig = c->ntries < UWSPR_NJIG ? c->ntries : UWSPR_NJIG;
+  if (c->use_fused || njig < UWSPR_NJIG) {   // (a lazy staged pass is resumed by the fused kernel)
     if (c->sched_grid <= 0) c->sched_grid = c->num_cus;   // one 16-wave workgroup per CU
     if ((rc = ensure(c, &c->d_tabs, &c->cap_tabs, (size_t)c->sched_grid * kSchedTabFloats))) return rc;
     if (!c->d_counter) HIPCHK(c, hipMalloc((void **)&c->d_counter, 64));
+  }
+  if (c->use_fused) {
+    // k6_sched: one workgroup per candidate, S0..S5 back to back
     if (getenv("UWSPR_SCHED_STAMPS") && atoi(getenv("UWSPR_SCHED_STAMPS")) &&
         (rc = ensure(c, &c->d_sched_stamps, &c->cap_sched_stamps, nslots * 64))) return rc;
     if ((rc = ensure(c, &c->d_dout, &c->cap_dout, nslots))) return rc;
@@ -717,8 +718,10 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
   c->cur_dout = user_out ? user_out : c->d_dout;
   dev_hyp *half[2] = {c->d_hyps, c->d_hyps + nslots * UWSPR_NJIG};
   launch_sched_init(c, dcands, dnpk, cand_stride, B, per_frame);
+  const bool lazy = njig < UWSPR_NJIG;   // only tries idt < njig of stage 5, packed njig per slot
+  if (lazy && (rc = ensure(c, &c->d_pwin, &c->cap_pwin, nslots * UWSPR_NSYM * 4))) return rc;
   for (int s = 0; s < 6; s++) {
-    const int H = (int)(nslots * hpc[s]);
+    const int H = (int)(nslots * (s == 5 ? njig : hpc[s]));
     const dev_hyp *h = half[s & 1];
     // lag sweeps (S0, S3, the 17 jiggered shifts) share their tone phasors
     const bool use_groups = c->use_lag_groups;
@@ -734,6 +737,7 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
       done = launch_tonecorr_stage_grid(c, dframes, B, (int)nslots, c->d_cent, c->d_cent_frame, 1, zero1,
                                         2, dd2, c->d_p);
     if (done) { /* launched */ }
+    else if (lazy && s == 5) launch_tonecorr(c, dframes, B, h, H, c->d_p);   // few, unrelated lags: the plain kernel
     else if (c->use_fstage && (s == 1 || s == 4)) launch_tonecorr_fstage(c, dframes, B, h, (int)nslots, H, c->d_p);
     else if (use_groups && s == 3 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)nslots, 5, 16, H, c->d_p);
     else if (use_groups && s == 5 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, 8, H, c->d_p);
@@ -741,12 +745,16 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
     else if (use_groups && s == 5) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, H, c->d_p);
     else launch_tonecorr(c, dframes, B, h, H, c->d_p);
     if (s < 5) {
-      launch_fold_step(c, s + 1, (int)nslots);   // fold of stage s + transition to stage s+1
+      launch_fold_step(c, s + 1, (int)nslots, njig);   // fold of stage s + transition to stage s+1
     } else {
       launch_fold(c, h, c->d_p, H, c->d_sync, c->d_sym);
-      launch_sched_finish(c, (int)nslots);
+      launch_sched_finish(c, (int)nslots, njig);
+      if (lazy)   // try 0's tone magnitudes = the winner's: what uwspr_demod_resume starts from
+        HIPCHK(c, hipMemcpy2DAsync(c->d_pwin, UWSPR_NSYM * 16, c->d_p, (size_t)njig * UWSPR_NSYM * 16,
+                                   UWSPR_NSYM * 16, nslots, hipMemcpyDeviceToDevice, c->stream));
     }
   }
+  c->last_slots = (int)nslots; c->last_sched_B = B; c->last_sched_per_frame = per_frame;
   HIPCHK(c, hipGetLastError());
   return UWSPR_OK;
 }
@@ -886,8 +894,6 @@ extern "C" int uwspr_set_tries(uwspr_ctx *c, int ntries) {
   int rc = ready(c);
   if (rc) return rc;
   if (ntries < 1 || ntries > UWSPR_NJIG) return fail(c, UWSPR_ERR_ARG, "ntries=%d (1..%d)", ntries, UWSPR_NJIG);
-  if (ntries < UWSPR_NJIG && !c->use_fused)
-    return fail(c, UWSPR_ERR_UNSUPPORTED, "lazy tries need the fused schedule kernel (UWSPR_SCHED_FUSED=1)");
   c->ntries = ntries;
   return UWSPR_OK;
 }
@@ -897,7 +903,7 @@ extern "C" int uwspr_demod_resume(uwspr_ctx *c, const float *frames, int B, int 
   int rc = ready(c);
   if (rc) return rc;
   if (!need || !out || B <= 0 || max_per_frame <= 0) return fail(c, UWSPR_ERR_ARG, "need/out/B/max_per_frame");
-  if (!c->use_fused || !c->d_pwin || c->last_sched_B != B || c->last_sched_per_frame != max_per_frame)
+  if (!c->d_pwin || c->last_sched_B != B || c->last_sched_per_frame != max_per_frame)
     return fail(c, UWSPR_ERR_ARG, "uwspr_demod_resume follows a schedule call of the same batch made with uwspr_set_tries(< %d)", UWSPR_NJIG);
   const float *d;
   if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;

@@ -195,10 +195,10 @@ void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, floa
 // schedule stages; see k5_schedule.hip
 void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t *npk,
                        int cand_stride, int B, int per_frame);
-void launch_fold_step(uwspr_ctx *c, int stage, int ncand);
+void launch_fold_step(uwspr_ctx *c, int stage, int ncand, int njig = UWSPR_NJIG);
 void launch_pack_slabs(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t *npk,
                        const uwspr_demod_out *dout, int per_frame, int K, uint8_t *slab, int B);
-void launch_sched_finish(uwspr_ctx *c, int ncand);
+void launch_sched_finish(uwspr_ctx *c, int ncand, int njig = UWSPR_NJIG);
 // the whole schedule in one launch (k6_sched.hip); njig = mode-2 tries to produce (17 = all)
 void launch_sched_fused(uwspr_ctx *c, const float *frames, int B, const uwspr_candidate *cands,
                         const int32_t *npk, int cand_stride, int per_frame, uwspr_demod_out *out,

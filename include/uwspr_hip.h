@@ -262,7 +262,8 @@ int uwspr_demod_batch(uwspr_ctx *ctx, const float *frames, int B, int where,
  * vectors before the host sees any.  uwspr_set_tries(ctx, k), k < 17: the schedule calls that follow
  * produce only tries idt < k (the other entries of uwspr_demod_out are zero, so uwspr_decode_candidate
  * skips them) and keep what is needed to produce the rest later.  Try 0 repeats the hypothesis that won
- * the last stage, so k = 1 costs no correlation at all.
+ * the last stage: with the fused schedule kernel k = 1 costs no correlation at all, the staged form
+ * runs its last stage on the k wanted tries only.  Both forms are resumed by the fused kernel.
  * uwspr_demod_resume(ctx, frames, B, where, need, max_per_frame, out): for the slots b*max_per_frame+j
  * with need[...] != 0 of the LAST schedule call (same frames, B, max_per_frame) all 17 tries are
  * produced, byte-identical to what a k = 17 call gives; the other records are left alone.

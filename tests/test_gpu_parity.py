@@ -592,12 +592,15 @@ def test_coarse_search_tile_forms_agree(G, frames, monkeypatch):
                     assert ga[b, j].tobytes() == gb[b, j].tobytes()
 
 
-def test_lazy_tries_and_resume_equal_the_eager_schedule(G, frames, vec):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_lazy_tries_and_resume_equal_the_eager_schedule(G, frames, vec, monkeypatch, fused):
     """uwspr_set_tries(k) + uwspr_demod_resume: the reference stops at its first decoding try
     (cc:457-490).  Tries idt < k of the lazy pass are byte-identical to the eager ones, the
     rest is zero; after the resume the flagged records equal the eager records byte for byte
-    and the unflagged ones are untouched.  Host and device pointer forms."""
+    and the unflagged ones are untouched.  Host and device pointer forms; both schedule forms
+    (the staged form runs stage 5 on the k wanted tries only and is resumed by the fused kernel)."""
     import torch
+    monkeypatch.setenv("UWSPR_SCHED_FUSED", fused)
     cands = [vec["cands"][b, :int(vec["npk"][b])] for b in range(4)]
     per = max(len(c) for c in cands)
     c = G.Context()
