@@ -358,6 +358,8 @@ def main():
         _, _, ok1 = G.decode_batch(out1[:, 0], nthreads=nthr)
         # the records try 0 did not decode get their other tries from uwspr_demod_resume
         need = torch.from_numpy((~ok1.astype(bool)).astype(np.uint8)).to(dev)
+        lz[0]["ctx"].demod_resume(batches[0], need, lz[0]["out"], max_per_frame=1)   # first call: allocations
+        torch.cuda.synchronize()
         t3 = time.perf_counter()
         lz[0]["ctx"].demod_resume(batches[0], need, lz[0]["out"], max_per_frame=1)
         torch.cuda.synchronize()
