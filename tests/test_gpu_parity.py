@@ -71,6 +71,27 @@ def test_spectrogram_and_stats_bit_exact(ctx, oracle, frames):
         assert np.float32(noise[b]).tobytes() == np.float32(onoise).tobytes()
 
 
+@pytest.mark.parametrize("rows", ["29", "22", "5"])
+def test_spectrogram_rows_per_wavefront_and_wide_band(G, oracle, frames, monkeypatch, rows):
+    """K1 walks 29 consecutive rows per wavefront for large batches and 6 for small ones (the
+    batches of these tests): the large-batch walk, an uneven split (22: last group 18 rows) and a
+    short one give the same bytes as the oracle; so does the full (unpruned) pass C that a band
+    wider than +-64 columns selects (halfbandwidth = 60)."""
+    monkeypatch.setenv("UWSPR_K1_ROWS", rows)
+    for kw in ({}, {"halfbandwidth": 60}):
+        c = G.Context(**kw)
+        try:
+            c.fdr_batch(frames)
+            ps = c.fdr_spectrum(frames.shape[0])[0]
+            lo, w = c.info.band_lo, c.info.band_w
+        finally:
+            c.close()
+        f = oracle.FDR(**kw)
+        assert (lo >= 192 and lo + w <= 320) == (not kw)      # the default band takes the pruned pass
+        for b in range(frames.shape[0]):
+            assert ps[b].tobytes() == f.spectrogram(frames[b])[:, lo:lo + w].tobytes(), (rows, kw, b)
+
+
 def test_fdr_candidates_match_oracle(ctx, oracle, frames):
     """rows a5-a11: candidate lists, order, selection."""
     got = ctx.fdr_batch(frames)
