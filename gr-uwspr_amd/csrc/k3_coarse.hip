@@ -20,6 +20,17 @@
 //  * The spectrogram window the candidate can touch is staged once into LDS as
 //    float4 {sqrt ps[row][c-3], [c-1], [c+1], [c+3]} per (row, centre column c):
 //    one ds_read_b128 gather per symbol instead of four gathers + four sqrt.
+//  * Most nonlinear hypotheses cannot be accepted and are never evaluated (exactly):  a metric is
+//    ss/pow with |ss| <= pow up to rounding, so |sync| <= 1.0001, and the nonlinear rule accepts on
+//    sync/best > threshold (cc:392) -- impossible once the running best is >= 1.001/threshold
+//    (0.1001 at the flowgraph's threshold = 10).  While best > 0 it only grows, and it is at least
+//    the largest linear metric seen so far.  So: the linear metrics of all 130 cells first; c* = the
+//    first cell whose linear metric reaches the bound; every sequence is evaluated only for the cells
+//    before c* (where a nonlinear hypothesis may still win), and the rule is replayed over
+//    {all hypotheses of cells < c*} then {linear hypotheses of cells >= c*}.  On a real signal c* is
+//    the cell of the signal's own bin and timing (53 of 130 on the benchmark frames): 2 100 sequence
+//    evaluations instead of 4 940.  threshold <= 0, a requested metric grid, or a candidate whose
+//    linear metrics never reach the bound: everything is evaluated.
 //  * One lane = one (cell, sequence), 162 sequential steps, so ss and pow
 //    accumulate in the reference's order (cc:207-209): bit-identical metrics.
 //  * Wave 0 then replays the reference's ORDER-DEPENDENT running-best rule over
@@ -74,19 +85,20 @@ __device__ __forceinline__ float quad_swap2(float v) {
   return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
 }
 
-struct k3_lds_layout { size_t tile, sync, umap, total; };
+struct k3_lds_layout { size_t tile, sync, umap, misc, total; };
 __host__ __device__ inline k3_lds_layout k3_layout(const fdr_consts &f) {
   k3_lds_layout l;
   l.tile = 0;
   l.sync = l.tile + (f.k3_mode == K3_TILE_F1_HBM ? 0 : (size_t)f.n * f.tp * k3_unit(f.k3_mode));
   l.umap = l.sync + (size_t)UWSPR_NIFR * UWSPR_NK0 * f.umax * 4;
-  l.total = l.umap + (((size_t)UWSPR_NIFR * f.cell_hyps * 2 + 15) & ~(size_t)15);
+  l.misc = l.umap + (((size_t)UWSPR_NIFR * f.cell_hyps * 2 + 15) & ~(size_t)15);   // c* (all LDS is dynamic: the
+  l.total = l.misc + 16;                                                           //  kernel may use the full 160 KB)
   // after the evaluation the tile + offset-table range is reused for the expanded
   // metrics [64-value slices at K3_SLICE_PITCH] + 3 floats per slice: grow it if needed
   const size_t reuse = ((size_t)K3_SLICE_PITCH + 3) * (size_t)((f.ntot + 63) >> 6) * 4;
   if (reuse > l.sync) {
     const size_t extra = (reuse - l.sync + 15) & ~(size_t)15;
-    l.sync += extra; l.umap += extra; l.total += extra;
+    l.sync += extra; l.umap += extra; l.misc += extra; l.total += extra;
   }
   return l;
 }
@@ -109,6 +121,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   float *syncbuf = reinterpret_cast<float *>(smem + lay.sync);       // [130][umax]
   uint16_t *umap = reinterpret_cast<uint16_t *>(smem + lay.umap);    // [5][cell_hyps]
 
+  int &s_cstar = *reinterpret_cast<int *>(smem + lay.misc);
   const int tid = threadIdx.x;
   const int nwork = work[0];
 #ifdef K3_STAMPS
@@ -154,14 +167,33 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   t_b = clock64();
 #endif
 
-  // ---- one lane per (cell, distinct offset sequence) -------------------------
+  // ---- one lane per (cell, offset sequence) ------------------------------------------------
+  // Work items: first the linear hypotheses' sequences of all cells (NCELL * nlin items, reference
+  // order), then every sequence of cell 0, 1, 2, ...  Round 0 takes the first 1024 items; then c*
+  // is known and the item list ends after cell c* - 1.
   const int segstep = 2 * K3_SEG_SYMS * f.tp * UNIT;
-  const int neval = UWSPR_NIFR * UWSPR_NK0 * f.umax;
-  for (int g = tid; g < neval; g += K3_THREADS) {
-    const int cell = g / f.umax, u = g - cell * f.umax;
+  const int hc = f.cell_hyps;
+  constexpr int NCELL = UWSPR_NIFR * UWSPR_NK0;
+  const int nlin_items = NCELL * f.nlin;
+  const bool want_grid = syncgrid != nullptr && j < grid_cap;
+  // |sync| <= 1.0001 (648 roundings of 2^-24 each): no nonlinear acceptance once best >= bound
+  const float bound = (f.threshold > 0.0f && !want_grid) ? 1.001f / f.threshold : __builtin_inff();
+  int nitems = min(K3_THREADS, nlin_items + NCELL * f.umax);
+  int cstar = NCELL;
+  // (splitting the items left after round 0 evenly over the remaining rounds is slower: a round is
+  // latency-bound below ~12 wavefronts, so one full round + a short one beats two medium ones)
+  for (int base = 0; base < nitems; base += K3_THREADS) {
+    const int g = base + tid;
+    if (g < nitems) {
+    int cell, u;
+    if (g < nlin_items) {
+      cell = g / f.nlin;
+      u = umap[(cell / UWSPR_NK0) * hc + (g - cell * f.nlin)];
+    } else {
+      const int q = g - nlin_items;
+      cell = q / f.umax; u = q - cell * f.umax;
+    }
     const int ifr_i = cell / UWSPR_NK0, k0 = cell - ifr_i * UWSPR_NK0;
-    // the sequence as 16-bit BYTE offsets into the tile, relative to the (row k0, this cell's
-    // centre) float4 of the current 32-symbol segment (k3_seq_entry): a gather address is one add
     const seq_ptr ot = uo_base + (ifr_i * f.umax + u) * (K3_SEQ_WORDS / 4);
     tile_bytes tb = (MODE == K3_TILE_F4 ? (tile_bytes)reinterpret_cast<const char *>(tile)
                                         : (tile_bytes)(uintptr_t)tile1) + (k0 * f.tp + ifr_i) * UNIT;
@@ -208,15 +240,36 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
       wa = wb; wb = wc;
       if (k8 + 3 < K3_SEQ_WORDS / 4) wc = ot[k8 + 3];
     }
-    syncbuf[g] = ieee_divf(ss, pw);  // cc:357,390
+    syncbuf[cell * f.umax + u] = ieee_divf(ss, pw);  // cc:357,390 (a sequence evaluated twice writes the same value twice)
+    }
+    if (base == 0) {
+      // c*: first cell (reference order) with a linear metric >= bound; NaN never compares true
+      __syncthreads();
+      if (tid < 64) {
+        int first = NCELL * f.nlin;
+        for (int blk = 0; blk < nlin_items && first == NCELL * f.nlin; blk += 64) {
+          const int q = blk + tid;
+          bool hit = false;
+          if (q < nlin_items) {
+            const int c = q / f.nlin;
+            hit = syncbuf[c * f.umax + umap[(c / UWSPR_NK0) * hc + (q - c * f.nlin)]] >= bound;
+          }
+          const unsigned long long m = __ballot(hit);
+          if (m != 0ull) first = blk + __ffsll((long long)m) - 1;
+        }
+        if (tid == 0) s_cstar = first / f.nlin;   // NCELL when no linear metric reaches the bound
+      }
+      __syncthreads();
+      cstar = s_cstar;
+      nitems = nlin_items + cstar * f.umax;
+    }
   }
   __syncthreads();
 #ifdef K3_STAMPS
   t_c = clock64();
 #endif
 
-  const int hc = f.cell_hyps;
-  if (syncgrid != nullptr && j < grid_cap) {
+  if (want_grid) {   // (cstar == NCELL: every sequence was evaluated)
     float *gout = syncgrid + ((size_t)b * grid_cap + j) * f.ntot;
     for (int g = tid; g < f.ntot; g += K3_THREADS) {
       const int cell = g / hc, h = g - cell * hc;
@@ -236,20 +289,22 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   //      rises with v for best > 0 and falls for best < 0), so a slice whose
   //      extreme value fails cannot contain an acceptance and is skipped -- and
   //      only slices that may accept are scanned value by value with ballots.
+  // The list that is replayed, in reference order: entries e < nfull = c* x hc are all hypotheses of
+  // the cells before c*; the rest are the nlin linear hypotheses of each cell from c* on.
+  const int nfull = cstar * hc;
+  const int ne = nfull + (NCELL - cstar) * f.nlin;
+  auto cell_h = [&](int e, int &cell, int &h) {
+    if (e < nfull) { cell = e / hc; h = e - cell * hc; }
+    else { const int r = e - nfull; cell = cstar + r / f.nlin; h = r - (cell - cstar) * f.nlin; }
+  };
   float *full = reinterpret_cast<float *>(smem);                       // [nslice][K3_SLICE_PITCH]
-  const int nslice = (f.ntot + 63) >> 6;
+  const int nslice = (ne + 63) >> 6;
   float *ssum = full + (size_t)nslice * K3_SLICE_PITCH;                // [nslice][3]
-  {
-    // (1a) expansion, consecutive lanes = consecutive hypotheses (conflict-free LDS traffic):
-    // thread walks g = tid, tid + 1024, ...: (cell, h) advance by carry, no division in the loop
-    const int qstep = K3_THREADS / hc, rstep = K3_THREADS - qstep * hc;
-    int cell = tid / hc, h = tid - cell * hc;
-    for (int g = tid; g < f.ntot; g += K3_THREADS) {
-      const int ifr_i = cell / UWSPR_NK0;  // constant divisor
-      full[g + (g >> 6) * (K3_SLICE_PITCH - 64)] = syncbuf[cell * f.umax + umap[ifr_i * hc + h]];
-      cell += qstep; h += rstep;
-      if (h >= hc) { h -= hc; cell += 1; }
-    }
+  // (1a) expansion, consecutive lanes = consecutive entries (conflict-free LDS traffic)
+  for (int e = tid; e < ne; e += K3_THREADS) {
+    int cell, h;
+    cell_h(e, cell, h);
+    full[e + (e >> 6) * (K3_SLICE_PITCH - 64)] = syncbuf[cell * f.umax + umap[(cell / UWSPR_NK0) * hc + h]];
   }
   __syncthreads();
   {
@@ -273,8 +328,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
       for (int i = 0; i < 16; i++) {
         const float v = vv[i];
         // NaN never satisfies a predicate: keep it out of the extremes
-        const bool use = (g0 + i < f.ntot) && (v == v);
-        const bool lin = h < f.nlin;
+        const bool use = (g0 + i < ne) && (v == v);
+        const bool lin = (g0 + i >= nfull) || h < f.nlin;
         mlin = fmaxf(mlin, (use && lin) ? v : ninf);
         mxnl = fmaxf(mxnl, (use && !lin) ? v : ninf);
         mnnl = fminf(mnnl, (use && !lin) ? v : pinf);
@@ -313,9 +368,9 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
       if (hit < 0) break;
       // exact scan of slice `hit`
       const int g = hit * 64 + tid;
-      const bool in = g < f.ntot;
+      const bool in = g < ne;
       const float v = in ? full[hit * K3_SLICE_PITCH + tid] : 0.0f;
-      const bool lin = in && (g % hc) < f.nlin;
+      const bool lin = in && (g >= nfull || (g % hc) < f.nlin);
       int start = 0;
       for (;;) {
         const bool pred = in && tid >= start &&
@@ -332,7 +387,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
     if (tid == 0) {
       cand->sync = best;
       if (gbest >= 0) {
-        const int cell = gbest / hc, h = gbest - cell * hc;
+        int cell, h;
+        cell_h(gbest, cell, h);
         const int ifr_i = cell / UWSPR_NK0, k0 = cell - ifr_i * UWSPR_NK0;
         cand->shift = 128 * k0;                                // cc:361,397
         cand->freq = (float)(if0 - 2 + ifr_i - f.m) * f.df;    // cc:362,398

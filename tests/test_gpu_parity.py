@@ -582,6 +582,30 @@ def test_other_carrier_and_frame_parameters(G, oracle):
                         assert (o["symbols"] == d["symbols"]).all(), (kw, b, j)
 
 
+@pytest.mark.parametrize("threshold", [0, 1, 3, 10, 50, 10 ** 6])
+def test_coarse_search_pruning_is_exact_for_every_threshold(G, oracle, threshold):
+    """K3 evaluates the nonlinear hypotheses only for the cells before the first linear metric
+    >= 1.001/threshold (no nonlinear acceptance is possible after it: |sync| <= 1, rule cc:392).
+    The candidates must equal the oracle's -- which evaluates everything -- for thresholds that
+    prune nothing (0, 1), some (3, 10, 50) or almost everything (1e6), on strong, weak and
+    signal-free frames, with and without linear drift hypotheses."""
+    fr = np.concatenate([G.synth.make_frames(3, seed=31337, snr_db=-16.0),
+                         G.synth.make_frames(3, seed=31338, snr_db=-28.0),
+                         (0.5 * np.random.default_rng(5).standard_normal((2, 45000, 2))).astype(np.float32)])
+    for maxdrift in (0, 2):
+        c = G.Context(threshold=threshold, maxdrift=maxdrift)
+        try:
+            got = c.fdr_batch(fr)
+        finally:
+            c.close()
+        f = oracle.FDR(threshold=threshold, maxdrift=maxdrift)
+        for b in range(fr.shape[0]):
+            exp = f.transform(fr[b])
+            assert len(got[b]) == len(exp), (threshold, maxdrift, b)
+            for a, e in zip(got[b], exp):
+                cand_equal(a, e)
+
+
 def test_coarse_search_tile_forms_agree(G, frames, monkeypatch):
     """K3's three tile forms (float4 per centre in LDS -- the default --, plain sqrt rows in LDS,
     sqrt rows in HBM: UWSPR_K3_TILE = 0 / 1 / 2) and a padded row pitch (UWSPR_K3_PITCH): identical
