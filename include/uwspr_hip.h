@@ -195,7 +195,8 @@ int uwspr_fdr_read_spectrum(uwspr_ctx *ctx, int B, float *ps_band, float *psavg,
                             float *smraw, float *smspec, float *noise);
 /* When enabled, the next uwspr_fdr_batch also keeps every hypothesis metric:
  * grid [B][ncand_cap][5][26][cell_hyps] (cc:357,390), read back with
- * uwspr_fdr_read_syncgrid.  Off by default (it is 65 KB per candidate). */
+ * uwspr_fdr_read_syncgrid.  Off by default: it is 65 KB per candidate, and the coarse search then has to
+ * evaluate every hypothesis instead of only those that can still be accepted (same candidates either way). */
 int uwspr_fdr_keep_syncgrid(uwspr_ctx *ctx, int ncand_cap);
 int uwspr_fdr_read_syncgrid(uwspr_ctx *ctx, int B, float *grid);
 
