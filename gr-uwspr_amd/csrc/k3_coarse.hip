@@ -169,8 +169,9 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
 
   // ---- one lane per (cell, offset sequence) ------------------------------------------------
   // Work items: first the linear hypotheses' sequences of all cells (NCELL * nlin items, reference
-  // order), then every sequence of cell 0, 1, 2, ...  Round 0 takes the first 1024 items; then c*
-  // is known and the item list ends after cell c* - 1.
+  // order), then every sequence of cell 0, 1, 2, ...  The first round(s) cover the linear items (one
+  // round of 1024 at the defaults, filled up with full-set items); then c* is known and the item
+  // list ends after cell c* - 1.
   const int segstep = 2 * K3_SEG_SYMS * f.tp * UNIT;
   const int hc = f.cell_hyps;
   constexpr int NCELL = UWSPR_NIFR * UWSPR_NK0;
@@ -178,8 +179,10 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   const bool want_grid = syncgrid != nullptr && j < grid_cap;
   // |sync| <= 1.0001 (648 roundings of 2^-24 each): no nonlinear acceptance once best >= bound
   const float bound = (f.threshold > 0.0f && !want_grid) ? 1.001f / f.threshold : __builtin_inff();
-  int nitems = min(K3_THREADS, nlin_items + NCELL * f.umax);
+  // the rounds that cover the linear items (one at the defaults), filled up with full-set items
+  int nitems = min(nlin_items + NCELL * f.umax, (nlin_items + K3_THREADS - 1) / K3_THREADS * K3_THREADS);
   int cstar = NCELL;
+  bool have_cstar = false;
   // (splitting the items left after round 0 evenly over the remaining rounds is slower: a round is
   // latency-bound below ~12 wavefronts, so one full round + a short one beats two medium ones)
   for (int base = 0; base < nitems; base += K3_THREADS) {
@@ -242,7 +245,8 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
     }
     syncbuf[cell * f.umax + u] = ieee_divf(ss, pw);  // cc:357,390 (a sequence evaluated twice writes the same value twice)
     }
-    if (base == 0) {
+    if (!have_cstar && base + K3_THREADS >= nlin_items) {   // every linear metric is in syncbuf now
+      have_cstar = true;
       // c*: first cell (reference order) with a linear metric >= bound; NaN never compares true
       __syncthreads();
       if (tid < 64) {

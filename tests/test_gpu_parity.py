@@ -588,11 +588,12 @@ def test_coarse_search_pruning_is_exact_for_every_threshold(G, oracle, threshold
     >= 1.001/threshold (no nonlinear acceptance is possible after it: |sync| <= 1, rule cc:392).
     The candidates must equal the oracle's -- which evaluates everything -- for thresholds that
     prune nothing (0, 1), some (3, 10, 50) or almost everything (1e6), on strong, weak and
-    signal-free frames, with and without linear drift hypotheses."""
+    signal-free frames, without and with linear drift hypotheses (maxdrift = 4: the 1 170 linear
+    sequences alone need more than one round of the kernel)."""
     fr = np.concatenate([G.synth.make_frames(3, seed=31337, snr_db=-16.0),
                          G.synth.make_frames(3, seed=31338, snr_db=-28.0),
                          (0.5 * np.random.default_rng(5).standard_normal((2, 45000, 2))).astype(np.float32)])
-    for maxdrift in (0, 2):
+    for maxdrift in (0, 2, 4):
         c = G.Context(threshold=threshold, maxdrift=maxdrift)
         try:
             got = c.fdr_batch(fr)
