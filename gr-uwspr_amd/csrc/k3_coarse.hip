@@ -37,7 +37,7 @@
 //    all 16380 hypotheses in reference order (strict > for linear cc:360, ratio
 //    against the running best for nonlinear cc:392) with ballots: 64 hypotheses
 //    per step, serialising only on acceptances.
-// One 1024-thread workgroup per candidate; everything between the spectrogram
+// One 512-thread workgroup per candidate; everything between the spectrogram
 // tile read and the 48-byte candidate record stays in LDS.
 // Roofline: LDS-gather / VALU bound; HBM traffic is the tile once (~60 KB).
 #include <algorithm>
@@ -49,7 +49,13 @@
 
 namespace uwspr {
 
-constexpr int K3_THREADS = 1024;
+// 8 wavefronts per candidate: alone the kernel is as fast as with 16 (52 vs 50 us: its rounds are latency-bound),
+// and it leaves half of a CU's register file to the other lanes' kernels while more than half of its own
+// wavefront cycles are waits (+2.4 % frames/s under three streams; 4 wavefronts: 74 us alone, slower overall)
+#ifndef K3_THREADS_N
+#define K3_THREADS_N 512
+#endif
+constexpr int K3_THREADS = K3_THREADS_N;
 // Offset sequences: per (ifr row, distinct sequence) K3_SEQ_WORDS words = 168 x u16 (162 used; 16-B loads), entry k =
 // byte offset of the symbol's float4 in the tile relative to the float4 of (row k0 + 2*32*(k/32), the
 // cell's own centre column): ((2*(k mod 32))*tp + (ifd-ifr)[k] - off_min) * 16, tp = tile row pitch in
@@ -104,7 +110,7 @@ __host__ __device__ inline k3_lds_layout k3_layout(const fdr_consts &f) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(K3_THREADS) void k3_coarse(
+__global__ __launch_bounds__(K3_THREADS, 1024 / K3_THREADS) void k3_coarse(
     const float *__restrict__ ps, fdr_consts f, const uint32_t *__restrict__ uoff_tab,
     const uint16_t *__restrict__ umap_tab, uwspr_candidate *__restrict__ cands,
     const int32_t *__restrict__ work, float *__restrict__ syncgrid, int grid_cap,
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(K3_THREADS) void k3_coarse(
   // ---- one lane per (cell, offset sequence) ------------------------------------------------
   // Work items: first the linear hypotheses' sequences of all cells (NCELL * nlin items, reference
   // order), then every sequence of cell 0, 1, 2, ...  The first round(s) cover the linear items (one
-  // round of 1024 at the defaults, filled up with full-set items); then c* is known and the item
+  // round of K3_THREADS at the defaults, filled up with full-set items); then c* is known and the item
   // list ends after cell c* - 1.
   const int segstep = 2 * K3_SEG_SYMS * f.tp * UNIT;
   const int hc = f.cell_hyps;
