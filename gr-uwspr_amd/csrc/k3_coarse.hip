@@ -34,9 +34,9 @@
 //  * One lane = one (cell, sequence), 162 sequential steps, so ss and pow
 //    accumulate in the reference's order (cc:207-209): bit-identical metrics.
 //  * Wave 0 then replays the reference's ORDER-DEPENDENT running-best rule over
-//    all 16380 hypotheses in reference order (strict > for linear cc:360, ratio
-//    against the running best for nonlinear cc:392) with ballots: 64 hypotheses
-//    per step, serialising only on acceptances.
+//    the hypotheses that can still be accepted, in reference order (strict > for
+//    linear cc:360, ratio against the running best for nonlinear cc:392) with
+//    ballots: 64 hypotheses per step, serialising only on acceptances.
 // One 512-thread workgroup per candidate; everything between the spectrogram
 // tile read and the 48-byte candidate record stays in LDS.
 // Roofline: LDS-gather / VALU bound; HBM traffic is the tile once (~60 KB).
