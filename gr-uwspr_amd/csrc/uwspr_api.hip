@@ -910,7 +910,8 @@ extern "C" int uwspr_demod_resume(uwspr_ctx *c, const float *frames, int B, int 
   const size_t nslots = (size_t)B * max_per_frame;
   const uint8_t *dneed = need;
   uwspr_demod_out *dout = out;
-  if (where == UWSPR_HOST) {
+  const bool host_io = where != UWSPR_DEVICE;   // UWSPR_DEVICE_FRAMES: frames in HBM, need / out in host memory
+  if (host_io) {
     if ((rc = ensure(c, &c->d_need, &c->cap_need, nslots))) return rc;
     HIPCHK(c, hipMemcpyAsync(c->d_need, need, nslots, hipMemcpyHostToDevice, c->stream));
     dneed = c->d_need;
@@ -918,7 +919,7 @@ extern "C" int uwspr_demod_resume(uwspr_ctx *c, const float *frames, int B, int 
   }
   launch_sched_fused(c, d, B, nullptr, nullptr, 0, max_per_frame, dout, UWSPR_NJIG, dneed);
   HIPCHK(c, hipGetLastError());
-  if (where == UWSPR_HOST) {
+  if (host_io) {
     HIPCHK(c, hipMemcpyAsync(out, c->d_dout, nslots * sizeof(uwspr_demod_out), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }

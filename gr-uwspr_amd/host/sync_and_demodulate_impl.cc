@@ -5,6 +5,9 @@
 // the frame(s) in one uwspr_demod_batch call (set_batch(n): n candidates PDUs per call; frames
 // that FDR left on the device are read there); the gate/retry/Fano loop (cc:457-490)
 // is replayed on the host by uwspr_decode_batch (uwspr_decode_candidate per record).
+// Like the reference, which stops at the first of its 17 jiggered shifts that decodes, the
+// schedule first produces try 0 only (uwspr_set_tries(1)); the records Fano rejects get their
+// other 16 tries from uwspr_demod_resume and a second Fano pass.  Same blobs, in the same order.
 #include <stdio.h>
 #include <string.h>
 #include <time.h>
@@ -32,6 +35,12 @@ class sync_and_demodulate_impl : public sync_and_demodulate {
     if (rc != UWSPR_OK) {
       std::string msg = d_ctx ? uwspr_last_error(d_ctx) : uwspr_status_string(rc);
       if (d_ctx) uwspr_ctx_destroy(d_ctx);
+      d_ctx = nullptr;
+      throw std::runtime_error("uwspr.sync_and_demodulate: " + msg);
+    }
+    if (uwspr_set_tries(d_ctx, 1) != UWSPR_OK) {
+      std::string msg = uwspr_last_error(d_ctx);
+      uwspr_ctx_destroy(d_ctx);
       d_ctx = nullptr;
       throw std::runtime_error("uwspr.sync_and_demodulate: " + msg);
     }
@@ -80,15 +89,18 @@ class sync_and_demodulate_impl : public sync_and_demodulate {
     for (int b = 1; b < B && on_device; b++)
       on_device = d_pending[b]->dev.ptr == d_pending[0]->dev.ptr + (size_t)b * d_fl * 2;
     int rc;
+    std::vector<float> frames;
+    const float *fptr;
+    int where;
     if (on_device) {
-      rc = uwspr_demod_batch(d_ctx, d_pending[0]->dev.ptr, B, UWSPR_DEVICE_FRAMES, cands.data(), npk.data(), per,
-                             per, out.data());
+      fptr = d_pending[0]->dev.ptr; where = UWSPR_DEVICE_FRAMES;
     } else {
-      std::vector<float> frames((size_t)B * d_fl * 2);
+      frames.resize((size_t)B * d_fl * 2);
       for (int b = 0; b < B; b++)   // cc:344-345: std::complex<float> is the (I,Q) pair
         memcpy(&frames[(size_t)b * d_fl * 2], d_pending[b]->samples->samples.data(), (size_t)d_fl * 2 * sizeof(float));
-      rc = uwspr_demod_batch(d_ctx, frames.data(), B, UWSPR_HOST, cands.data(), npk.data(), per, per, out.data());
+      fptr = frames.data(); where = UWSPR_HOST;
     }
+    rc = uwspr_demod_batch(d_ctx, fptr, B, where, cands.data(), npk.data(), per, per, out.data());
     if (rc != UWSPR_OK)
       throw std::runtime_error(std::string("uwspr.sync_and_demodulate: ") + uwspr_last_error(d_ctx));
     // cc:389: the candidates are independent, so their Fano runs go to the host
@@ -98,6 +110,26 @@ class sync_and_demodulate_impl : public sync_and_demodulate {
     std::vector<uint8_t> got(n);
     if (uwspr_decode_batch(out.data(), n, 0, msgs.data(), nullptr, got.data()) < 0)
       throw std::runtime_error("uwspr.sync_and_demodulate: decode_batch");
+    // cc:457-490: try 0 did not decode -> the other jiggered shifts of those candidates
+    std::vector<uint8_t> need(n, 0);
+    std::vector<int> again;
+    for (int i = 0; i < n; i++)
+      if (out[i].worth_a_try && !got[i]) { need[i] = 1; again.push_back(i); }
+    if (!again.empty()) {
+      rc = uwspr_demod_resume(d_ctx, fptr, B, where, need.data(), per, out.data());
+      if (rc != UWSPR_OK)
+        throw std::runtime_error(std::string("uwspr.sync_and_demodulate: ") + uwspr_last_error(d_ctx));
+      std::vector<uwspr_demod_out> sub(again.size());
+      for (size_t q = 0; q < again.size(); q++) sub[q] = out[again[q]];
+      std::vector<int8_t> m2(again.size() * 7);
+      std::vector<uint8_t> g2(again.size());
+      if (uwspr_decode_batch(sub.data(), (int)again.size(), 0, m2.data(), nullptr, g2.data()) < 0)
+        throw std::runtime_error("uwspr.sync_and_demodulate: decode_batch");
+      for (size_t q = 0; q < again.size(); q++) {
+        got[again[q]] = g2[q];
+        memcpy(&msgs[(size_t)again[q] * 7], &m2[q * 7], 7);
+      }
+    }
     for (int b = 0; b < B; b++) {
       for (int j = 0; j < npk[b]; j++) {
         if (!got[(size_t)b * per + j]) continue;

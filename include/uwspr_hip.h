@@ -41,7 +41,7 @@ typedef enum {
   UWSPR_ERR_NODEVICE = -7     /* no usable gfx950 device: there is NO CPU fallback */
 } uwspr_status;
 
-/* UWSPR_DEVICE_FRAMES (uwspr_fdr_batch, uwspr_demod_batch, uwspr_pipeline_batch): the frames are device
+/* UWSPR_DEVICE_FRAMES (uwspr_fdr_batch, uwspr_demod_batch, uwspr_pipeline_batch, uwspr_demod_resume): the frames are device
  * memory (e.g. what uwspr_stream_take returned), every other pointer of the call is host memory. */
 enum { UWSPR_HOST = 0, UWSPR_DEVICE = 1, UWSPR_DEVICE_FRAMES = 2 };
 enum { UWSPR_LINEAR = 0, UWSPR_NONLINEAR = 1 };   /* enum Modes, lib/candidate_t.h:36 */
@@ -268,7 +268,7 @@ int uwspr_demod_batch(uwspr_ctx *ctx, const float *frames, int B, int where,
  * uwspr_demod_resume(ctx, frames, B, where, need, max_per_frame, out): for the slots b*max_per_frame+j
  * with need[...] != 0 of the LAST schedule call (same frames, B, max_per_frame) all 17 tries are
  * produced, byte-identical to what a k = 17 call gives; the other records are left alone.
- * where == UWSPR_HOST: need is host memory and `out` receives all B*max_per_frame records;
+ * where == UWSPR_HOST (or UWSPR_DEVICE_FRAMES): need is host memory and `out` receives all B*max_per_frame records;
  * UWSPR_DEVICE: need and out are device memory, out being the buffer the first call wrote. */
 int uwspr_set_tries(uwspr_ctx *ctx, int ntries);
 int uwspr_demod_resume(uwspr_ctx *ctx, const float *frames, int B, int where, const uint8_t *need,

@@ -3,8 +3,10 @@
 // the resampler):  stream -> sliding_window_stream_to_pdu(375,45000,9,2)
 //   -> FDR(375,45000,256,0,200,10,1500,10) -> sync_and_demodulate(375,45000,256,0,200,1500)
 //   -> WSPR_unpacker() -> sink
-// modes:  framer | errors | decode <file.c2> | stream <file.c2>
+// modes:  framer | errors | decode <file.c2> | stream <file.c2> | weak <file.c2> <sigma>
+#include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <stdexcept>
@@ -124,7 +126,71 @@ static int stream(const char *path) {
   return 0;
 }
 
+// The .c2 frame under heavy noise, eight independent copies: through the block mirror (which
+// produces try 0 first and resumes the records Fano rejects) and through the C ABI with all 17
+// tries at once.  Prints the decoded blobs of both ways and the try each eager decode used.
+static int weak(const char *path, double sigma) {
+  std::vector<float> iq(2 * 45000);
+  if (uwspr_c2_read(path, iq.data(), nullptr, nullptr) != 0) { printf("cannot read %s\n", path); return 2; }
+  const int NB = 8;
+  std::vector<float> frames((size_t)NB * 2 * 45000);
+  unsigned long long st = 88172645463325252ull;
+  auto u01 = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return (double)(st >> 11) / 9007199254740992.0; };
+  for (size_t i = 0; i < frames.size(); i += 2) {       // Box-Muller, two normals per complex sample
+    const double r = sqrt(-2.0 * log(u01() + 1e-300)), a = 6.283185307179586 * u01();
+    frames[i] = iq[i % (2 * 45000)] + (float)(sigma * r * cos(a));
+    frames[i + 1] = iq[(i + 1) % (2 * 45000)] + (float)(sigma * r * sin(a));
+  }
+  // (a) the mirror: FDR -> sync_and_demodulate, all eight PDUs in one device call
+  auto fdr = FDR::make(375, 45000, 256, 0, 200, 10, 1500, 10);
+  auto sad = sync_and_demodulate::make(375, 45000, 256, 0, 200, 1500);
+  message_sink blobs;
+  block::msg_connect(fdr.get(), "out", sad.get(), "in");
+  block::msg_connect(sad.get(), "out", &blobs, "in");
+  fdr->set_batch(NB); sad->set_batch(NB);
+  for (int b = 0; b < NB; b++) {
+    auto pdu = std::make_shared<samples_pdu>();
+    pdu->samples.resize(45000);
+    for (int i = 0; i < 45000; i++)
+      pdu->samples[i] = gr_complex(frames[((size_t)b * 45000 + i) * 2], frames[((size_t)b * 45000 + i) * 2 + 1]);
+    fdr->post("in", pdu);
+  }
+  fdr->flush(); sad->flush();
+  for (auto &m : blobs.received) {
+    auto bl = std::dynamic_pointer_cast<const blob_pdu>(m);
+    printf("mirror");
+    for (int i = 0; i < 7; i++) printf(" %02x", (unsigned)(unsigned char)bl->bytes[i]);
+    printf("\n");
+  }
+  // (b) the C ABI, every try produced before the host sees any
+  uwspr_params p = {375, 45000, 256, 0, 200, 10, 1500, 10};
+  uwspr_ctx *c = nullptr;
+  if (uwspr_ctx_create(&p, 0, &c) != UWSPR_OK) { printf("ctx\n"); return 3; }
+  const int per = 26;
+  std::vector<uwspr_candidate> cands((size_t)NB * 200);
+  std::vector<int32_t> npk(NB);
+  std::vector<uwspr_demod_out> out((size_t)NB * per);
+  if (uwspr_pipeline_batch(c, frames.data(), NB, UWSPR_HOST, per, cands.data(), npk.data(), out.data()) != UWSPR_OK) {
+    printf("pipeline: %s\n", uwspr_last_error(c)); return 4;
+  }
+  std::vector<int8_t> msgs((size_t)NB * per * 7);
+  std::vector<int32_t> idt((size_t)NB * per);
+  std::vector<uint8_t> got((size_t)NB * per);
+  uwspr_decode_batch(out.data(), NB * per, 0, msgs.data(), idt.data(), got.data());
+  for (int b = 0; b < NB; b++)
+    for (int j = 0; j < npk[b] && j < per; j++) {
+      const size_t q = (size_t)b * per + j;
+      if (!got[q]) continue;
+      printf("eager");
+      for (int i = 0; i < 7; i++) printf(" %02x", (unsigned)(unsigned char)msgs[q * 7 + i]);
+      printf("\ntry %d\n", idt[q]);
+    }
+  uwspr_ctx_destroy(c);
+  return 0;
+}
+
 int main(int argc, char **argv) {
+  if (argc >= 4 && !strcmp(argv[1], "weak")) return weak(argv[2], atof(argv[3]));
   if (argc >= 3 && !strcmp(argv[1], "stream")) return stream(argv[2]);
   if (argc >= 2 && !strcmp(argv[1], "framer")) return framer();
   if (argc >= 2 && !strcmp(argv[1], "errors")) return errors();
