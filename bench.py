@@ -386,6 +386,16 @@ def main():
         for _ in range(3):
             ctx.pipeline_batch(frames_cpu, max_per_frame=1)
         host_rate = 3 * B / (time.perf_counter() - t2)
+    # ... from PAGE-LOCKED host memory (uwspr_host_alloc / any pinned buffer): one DMA per batch
+    host_pinned_rate = None
+    if frames_cpu is not None:
+        pinned = torch.from_numpy(frames_cpu).pin_memory()
+        pn = pinned.numpy()
+        ctx.pipeline_batch(pn, max_per_frame=1)
+        t2 = time.perf_counter()
+        for _ in range(3):
+            ctx.pipeline_batch(pn, max_per_frame=1)
+        host_pinned_rate = 3 * B / (time.perf_counter() - t2)
     # ... and as a continuous 375 S/s STREAM (uwspr_stream_*): every step uploads only the B x 3375 new
     # samples (pinned staging), the frames are cut on the device, every result goes back to the host
     stream_rate = None
@@ -475,6 +485,7 @@ def main():
             "kernels": kern,
             "lazy_s5": lazy,
             "host_pointer_frames_per_s_pcie_inclusive": host_rate,
+            "host_pinned_pointer_frames_per_s_pcie_inclusive": host_pinned_rate,
             "host_stream_frames_per_s_pcie_inclusive": stream_rate,
             "host_tail_fano": host_tail,
             "host_enqueue_ms_per_step": 1e3 * t_enq / K,

@@ -339,6 +339,14 @@ extern "C" int uwspr_synchronize(uwspr_ctx *c) {
 // transfer merely enqueued; whole batches of frames are left to the runtime's pageable path.
 static int upload(uwspr_ctx *c, void *dst, const void *src, size_t bytes) {
   const size_t PIECE = 8u << 20;
+  {   // the caller's buffer is already page-locked (uwspr_host_alloc, hipHostMalloc, hipHostRegister): plain DMA
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost) {
+      HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+      return UWSPR_OK;
+    }
+    (void)hipGetLastError();   // an ordinary pointer is "invalid value" to the query: not an error here
+  }
   if (bytes > 4 * PIECE) {   // a whole batch of frames: one host thread's memcpy into pinned memory (~10 GB/s)
     HIPCHK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));   // would be slower than the runtime's own staging (measured 57 k vs 87 k frames/s)
     return UWSPR_OK;
@@ -889,6 +897,12 @@ extern "C" int uwspr_device_alloc(size_t bytes, void **ptr) {
   return hipMalloc(ptr, bytes) == hipSuccess ? UWSPR_OK : UWSPR_ERR_NOMEM;
 }
 extern "C" void uwspr_device_free(void *ptr) { if (ptr) (void)hipFree(ptr); }
+
+extern "C" int uwspr_host_alloc(size_t bytes, void **ptr) {
+  if (!ptr) return UWSPR_ERR_ARG;
+  return hipHostMalloc(ptr, bytes, hipHostMallocDefault) == hipSuccess ? UWSPR_OK : UWSPR_ERR_NOMEM;
+}
+extern "C" void uwspr_host_free(void *ptr) { if (ptr) (void)hipHostFree(ptr); }
 
 extern "C" int uwspr_set_tries(uwspr_ctx *c, int ntries) {
   int rc = ready(c);

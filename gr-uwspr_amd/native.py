@@ -144,7 +144,7 @@ ABI_SYMBOLS = [
     "uwspr_ctx_create", "uwspr_ctx_destroy", "uwspr_last_error", "uwspr_status_string",
     "uwspr_get_info", "uwspr_set_stream", "uwspr_synchronize", "uwspr_frontend_batch",
     "uwspr_frontend_taps", "uwspr_stream_open", "uwspr_stream_push", "uwspr_stream_take", "uwspr_stream_reset",
-    "uwspr_device_alloc", "uwspr_device_free", "uwspr_fdr_batch",
+    "uwspr_device_alloc", "uwspr_device_free", "uwspr_host_alloc", "uwspr_host_free", "uwspr_fdr_batch",
     "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
     "uwspr_sync_sweep", "uwspr_sync_grid", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
     "uwspr_pipeline_batch", "uwspr_set_tries", "uwspr_demod_resume", "uwspr_pack_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
@@ -197,6 +197,9 @@ def lib():
     L.uwspr_device_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.uwspr_device_free.argtypes = [vp]
     L.uwspr_device_free.restype = None
+    L.uwspr_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.uwspr_host_free.argtypes = [vp]
+    L.uwspr_host_free.restype = None
     L.uwspr_fdr_batch.argtypes = [vp, vp, ip, ip, vp, vp]
     L.uwspr_fdr_read_spectrum.argtypes = [vp, ip, vp, vp, vp, vp, vp]
     L.uwspr_fdr_keep_syncgrid.argtypes = [vp, ip]

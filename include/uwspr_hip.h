@@ -177,6 +177,11 @@ int uwspr_stream_reset(uwspr_ctx *ctx, long long pos);
 /* device memory for callers without a HIP runtime of their own (the block mirror's frame hand-over) */
 int uwspr_device_alloc(size_t bytes, void **ptr);
 void uwspr_device_free(void *ptr);
+/* Page-locked host memory for frames handed over as host pointers: the upload is then one DMA at the
+ * link's rate instead of the runtime's staged copy of pageable memory (any page-locked buffer is
+ * recognised, whoever allocated it). */
+int uwspr_host_alloc(size_t bytes, void **ptr);
+void uwspr_host_free(void *ptr);
 
 /* ---- coarse search: FDR_impl::transform, FDR_impl.cc:214-456 ------------ */
 /* cands: [B][maxfreqs] records; npk: [B].  Same candidate order, fields and
