@@ -397,31 +397,39 @@ def main():
             ctx.pipeline_batch(pn, max_per_frame=1)
         host_pinned_rate = 3 * B / (time.perf_counter() - t2)
     # ... and as a continuous 375 S/s STREAM (uwspr_stream_*): every step uploads only the B x 3375 new
-    # samples (pinned staging), the frames are cut on the device, every result goes back to the host
+    # samples (from page-locked memory: one DMA), the frames are cut on the device, every result goes
+    # back to the host (page-locked buffers), one synchronisation per step.  (Running the ingest on a
+    # second HIP stream beside the search was tried: cross-stream event waits and copies in both
+    # directions made it anything from as fast to six times slower from run to run -- hardware-queue
+    # and copy-engine sharing -- so the measured form is the plain sequential one.)
     stream_rate = None
     if frames_cpu is not None:
         hop = 3375
         rng = np.random.default_rng(3)
-        chunk = (0.5 * rng.standard_normal((B * hop, 2))).astype(np.float32)
+        chunk = torch.from_numpy((0.5 * rng.standard_normal((B * hop, 2))).astype(np.float32)).pin_memory().numpy()
         ctx.stream_open(hop, B)
         ctx.stream_push(frames_cpu[0][: 45000 - hop])
         fr_t = torch.empty((B, 45000, 2), dtype=torch.float32, device=dev)
         ln0 = lanes[0]
+        hb = (torch.empty(B, dtype=torch.int32).pin_memory(), torch.empty(ln0["cands"].numel(), dtype=torch.uint8).pin_memory(),
+              torch.empty(ln0["out"].numel(), dtype=torch.uint8).pin_memory())
 
         def stream_step():
-            ctx.stream_push(chunk)
-            ctx.stream_take(B, fr_t)
             with torch.cuda.stream(ln0["stream"]):
+                ctx.stream_push(chunk)
+                ctx.stream_take(B, fr_t)
                 ln0["ctx"].pipeline_batch_into(fr_t, ln0["cands"], ln0["npk"], ln0["out"], max_per_frame=1)
+                hb[0].copy_(ln0["npk"], non_blocking=True)
+                hb[1].copy_(ln0["cands"], non_blocking=True)
+                hb[2].copy_(ln0["out"], non_blocking=True)
             ctx.synchronize()
-            return ln0["npk"].cpu(), ln0["cands"].cpu(), ln0["out"].cpu()
 
         if ln0["ctx"] is ctx:
             stream_step()
             t2 = time.perf_counter()
-            for _ in range(5):
+            for _ in range(8):
                 stream_step()
-            stream_rate = 5 * B / (time.perf_counter() - t2)
+            stream_rate = 8 * B / (time.perf_counter() - t2)
     if args.no_cpu:
         frames_cpu = None
     result = None
