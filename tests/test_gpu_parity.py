@@ -582,6 +582,43 @@ def test_other_carrier_and_frame_parameters(G, oracle):
                         assert (o["symbols"] == d["symbols"]).all(), (kw, b, j)
 
 
+@pytest.mark.parametrize("fl", [45056, 48000])
+def test_other_frame_lengths(G, oracle, fl):
+    """fl is a parameter of the reference's blocks (the row count of the spectrogram and the
+    sample bound np of the fine search follow it: FDR_impl.cc:118, sync_and_demodulate_impl.cc:205).
+    Two frames longer than the flowgraph's 45 000 samples (a shorter one has fewer than the 348 rows the
+    coarse search indexes: UWSPR_ERR_UNSUPPORTED; the reference reads out of bounds): spectrogram band,
+    candidates and the whole schedule against the oracle."""
+    base = G.synth.make_frames(3, seed=424242, snr_db=-17.0)
+    if fl <= base.shape[1]:
+        fr = np.ascontiguousarray(base[:, :fl])
+    else:
+        tail = (0.35 * np.random.default_rng(11).standard_normal((3, fl - base.shape[1], 2))).astype(np.float32)
+        fr = np.ascontiguousarray(np.concatenate([base, tail], axis=1))
+    c = G.Context(fl=fl)
+    try:
+        cands, out = c.pipeline_batch(fr, max_per_frame=2)
+        ps = c.fdr_spectrum(3)[0]
+        lo, w = c.info.band_lo, c.info.band_w
+    finally:
+        c.close()
+    f = oracle.FDR(fl=fl)
+    for b in range(3):
+        assert ps[b].tobytes() == f.spectrogram(fr[b])[:, lo:lo + w].tobytes(), (fl, b)
+        exp = f.transform(fr[b])
+        assert len(cands[b]) == len(exp) >= 1, (fl, b)
+        for j, (a, e) in enumerate(zip(cands[b], exp)):
+            cand_equal(a, e)
+            if j < 2:
+                d = oracle.demod_candidate(e, 1500, fr[b])
+                o = out[b, j]
+                assert int(o["worth_a_try"]) == d["worth_a_try"] and int(o["shift1"]) == d["shift1"], (fl, b, j)
+                for k in ("f1", "drift1", "sync1"):
+                    assert np.float32(o[k]).tobytes() == np.float32(d[k]).tobytes(), (fl, b, j, k)
+                if d["worth_a_try"]:
+                    assert (o["symbols"] == d["symbols"]).all(), (fl, b, j)
+
+
 @pytest.mark.parametrize("threshold", [0, 1, 3, 10, 50, 10 ** 6])
 def test_coarse_search_pruning_is_exact_for_every_threshold(G, oracle, threshold):
     """K3 evaluates the nonlinear hypotheses only for the cells before the first linear metric
