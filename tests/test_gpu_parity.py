@@ -559,7 +559,8 @@ def test_other_carrier_and_frame_parameters(G, oracle):
     frames = G.synth.make_frames(3, seed=271828, snr_db=-16.0, halfbandwidth=20)
     for kw in ({"cf": 2000, "halfbandwidth": 20}, {"cf": 3000, "halfbandwidth": 20},
                {"halfbandwidth": 30, "maxfreqs": 3, "maxdrift": 1}, {"cf": 500, "halfbandwidth": 12},
-               {"cf": 6000, "halfbandwidth": 20}, {"cf": 24000, "halfbandwidth": 20}):
+               {"cf": 6000, "halfbandwidth": 20}, {"cf": 24000, "halfbandwidth": 20},
+               {"fs": 400, "halfbandwidth": 12}):   # fs only moves the coarse bin width (FDR_impl.cc:93); the fine search keeps 375
         c = G.Context(**kw)
         try:
             cands, out = c.pipeline_batch(frames, max_per_frame=2)
