@@ -15,6 +15,23 @@ def _is_torch(x):
     return hasattr(x, "data_ptr") and hasattr(x, "is_cuda")
 
 
+class FrameView:
+    """B frames that are not a contiguous [B, fl, 2] array: either a raw device pointer (what
+    stream_take_view returns: frames in place in the stream buffer) or a host array holding a stretch
+    of the stream.  Frame b starts at 2*stride*b floats; pair with Context.set_frame_stride(stride)."""
+
+    def __init__(self, B, ptr=None, host=None, device=0):
+        self.B = int(B)
+        self.ptr = ptr
+        self.host = None if host is None else np.ascontiguousarray(host, dtype=np.float32)
+        self._dev = device
+
+    @property
+    def device(self):
+        import torch
+        return torch.device("cuda", self._dev)
+
+
 class Context:
     """Parameters mirror gr::uwspr::FDR::make / sync_and_demodulate::make
     (include/uwspr/FDR.h:49-50, include/uwspr/sync_and_demodulate.h:49)."""
@@ -56,6 +73,10 @@ class Context:
     # -- helpers -----------------------------------------------------------
     def _frames(self, frames):
         """-> (pointer, B, where, keepalive)"""
+        if isinstance(frames, FrameView):      # B frames at a raw pointer, pitch per set_frame_stride
+            if frames.host is not None:
+                return C.c_void_p(frames.host.ctypes.data), frames.B, N.HOST, frames.host
+            return C.c_void_p(frames.ptr), frames.B, N.DEVICE, frames
         if _is_torch(frames):
             assert frames.is_cuda and frames.is_contiguous() and frames.dtype.is_floating_point
             assert frames.element_size() == 4
@@ -250,6 +271,23 @@ class Context:
         fr = C.c_void_p()
         self._chk(self.L.uwspr_stream_take(self.h, int(nframes), C.c_void_p(into.data_ptr()), C.byref(fr), C.byref(pos)))
         return pos.value
+
+    def stream_take_view(self, nframes):
+        """The next nframes frames IN PLACE -> (device pointer, stride in samples, stream index of
+        the first frame).  Frame j starts at pointer + 8*stride*j bytes; valid until the next take.
+        Use with set_frame_stride(stride) and frames_ptr=... of the *_into calls."""
+        pos = C.c_longlong(0)
+        fr = C.c_void_p()
+        st = C.c_int(0)
+        self._chk(self.L.uwspr_stream_take_view(self.h, int(nframes), C.byref(fr), C.byref(st), C.byref(pos)))
+        return fr.value, st.value, pos.value
+
+    def stream_wait_uploads(self):
+        self._chk(self.L.uwspr_stream_wait_uploads(self.h))
+
+    def set_frame_stride(self, stride=0):
+        """Frame pitch in samples of the `frames` argument of the calls that follow (0 = fl)."""
+        self._chk(self.L.uwspr_set_frame_stride(self.h, int(stride)))
 
     def set_tries(self, ntries):
         """Mode-2 tries per candidate the schedule calls produce (17 = all; fewer = lazy)."""

@@ -62,7 +62,7 @@ __device__ unsigned long long k1_stamp_buf[3 * 16384];
 // register slots 0 and 7 (fft512_lane.h: pass_c_narrow), 9 % of the kernel's arithmetic less.
 template <bool NARROW>
 __global__ __launch_bounds__(64 * K1_WAVES, 3) void k1_spectrogram(
-    const float2 *__restrict__ frames, int B, int rpw, int fl, int n, const float *__restrict__ window,
+    const float2 *__restrict__ frames, int B, int rpw, int fstride, int n, const float *__restrict__ window,
     const float2 *__restrict__ twiddle, float *__restrict__ ps, int band_lo, int band_w,
     int32_t *__restrict__ work_count) {
   __shared__ cpx tw_s[256];
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * K1_WAVES, 3) void k1_spectrogram(
   const pass_tw twC = load_pass_tw(tw_s, L, 64);
   const cpx w64 = tw_s[64], w192 = tw_s[192];
 
-  const float2 *x = frames + (size_t)b * fl;
+  const float2 *x = frames + (size_t)b * fstride;
   cpx *lds = xch[wv];
   const int row0 = (item - b * gpf) * rpw;
   if (b >= B) { K1_STAMP(1) return; }   // wave-uniform; no workgroup barrier below
@@ -171,7 +171,7 @@ void launch_spectrogram(uwspr_ctx *c, const float *frames, int B) {
   const bool narrow = f.band_lo >= 192 && f.band_lo + f.band_w <= 320;
   auto go = [&](auto kern) {
     hipLaunchKernelGGL(kern, grid, dim3(64 * K1_WAVES), 0, c->stream,
-                       (const float2 *)frames, B, rpw, f.fl, f.n, c->d_window,
+                       (const float2 *)frames, B, rpw, c->fstride, f.n, c->d_window,
                        (const float2 *)c->d_twiddle, c->d_ps, f.band_lo, f.band_w, c->d_work);
   };
   if (narrow) go(k1_spectrogram<true>); else go(k1_spectrogram<false>);

@@ -55,7 +55,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 template <int T>
 __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
-    const float2 *__restrict__ frames, int fl, int nframes, const dev_hyp *__restrict__ hyps,
+    const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_hyp *__restrict__ hyps,
     int H, float *__restrict__ p_out) {
   constexpr int PPW = 16 * T;        // pairs per wavefront
   constexpr int LPP = 4 / T;         // lanes per pair
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
   const int own_i = mineA ? iA0 + pr : pr - sb;
   const bool own_ok = mineA ? okA : (okB && (g0 + pr) < total);
   const int own_nb = (mineA ? A.lag : Bh.lag) + 256 * own_i;  // first sample index
-  const bool interior = __all((own_nb > 0) && (own_nb + 255 < fl));
+  const bool interior = __all((own_nb > 0) && (own_nb + 255 < np));
 
   // ---- per-symbol tone phasor steps (binary64 angle, cc:173-189) ----------
   float cd[T], sd[T];
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
     const bool sA = seg < sb;
     const int fr = sA ? A.frame : Bh.frame;
     const int nb = sA ? A.lag + 256 * (iA0 + seg) : Bh.lag + 256 * (seg - sb);
-    src[t] = frames + ((long long)fr * fl + nb + kk);
+    src[t] = frames + ((long long)fr * fstride + nb + kk);
   }
 
   float2 stage[NLD];
@@ -139,10 +139,10 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
       for (int t = 0; t < NLD; t++) {
         const int seg = 4 * t + segq;
         const bool sA = seg < sb;
-        const long long fb = (long long)(sA ? A.frame : Bh.frame) * fl;
+        const long long fb = (long long)(sA ? A.frame : Bh.frame) * fstride;
         const int n = (sA ? A.lag + 256 * (iA0 + seg) : Bh.lag + 256 * (seg - sb)) + 16 * c + kk;
-        const bool inr = (n > 0) && (n < fl);  // cc:205, sample 0 excluded
-        float2 v = frames[fb + min(max(n, 0), fl - 1)];
+        const bool inr = (n > 0) && (n < np);  // cc:205, sample 0 excluded
+        float2 v = frames[fb + min(max(n, 0), np - 1)];
         // a skipped sample contributes nothing: x*c with x = 0 leaves inp/quad unchanged
         stage[t] = inr ? v : make_float2(0.0f, 0.0f);
       }
@@ -217,9 +217,9 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   dim3 blk(64 * K4_WAVES);
-  if (T == 1) launch_timed(c, ps, k4_tonecorr<1>, dim3(blocks), blk, 0, fr, c->fc.fl, B, hyps, H, po);
-  else if (T == 2) launch_timed(c, ps, k4_tonecorr<2>, dim3(blocks), blk, 0, fr, c->fc.fl, B, hyps, H, po);
-  else launch_timed(c, ps, k4_tonecorr<4>, dim3(blocks), blk, 0, fr, c->fc.fl, B, hyps, H, po);
+  if (T == 1) launch_timed(c, ps, k4_tonecorr<1>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po);
+  else if (T == 2) launch_timed(c, ps, k4_tonecorr<2>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po);
+  else launch_timed(c, ps, k4_tonecorr<4>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po);
 }
 
 }  // namespace uwspr
@@ -251,7 +251,7 @@ __device__ unsigned long long g_k4_stamps[K4_STAMP_WAVES * 4];
 
 template <int NL>
 __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
-    const float2 *__restrict__ frames, int fl, int nframes, const dev_grp *__restrict__ grps,
+    const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_grp *__restrict__ grps,
     int G, float *__restrict__ p_out) {
   constexpr int PPW = 16;                  // (group, symbol) pairs per wavefront, 4 tone lanes each
   constexpr int NLP = (NL + 1) & ~1;       // lags per sample slot, padded to even (16-B aligned slots)
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
 #pragma unroll
   for (int l = 0; l < NL; l++) {
     const int nb = (mineA ? la[l] : lb[l]) + 256 * own_i;
-    inside = inside && (nb > 0) && (nb + 255 < fl);
+    inside = inside && (nb > 0) && (nb + 255 < np);
   }
   const bool interior = __all(inside);
 
@@ -341,17 +341,17 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
   const int kk = lane & 15;
   const int segq = lane >> 4;
   // element offsets relative to the wave's first frame (wave-uniform base pointer)
-  const float2 *wbase = frames + (long long)frA * fl;
+  const float2 *wbase = frames + (long long)frA * fstride;
   int eoff[4];
   bool slotA[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int pj = 4 * j + segq;
     slotA[j] = pj < sb;
-    eoff[j] = slotA[j] ? 256 * (iA0 + pj) + kk : (frB - frA) * fl + 256 * (pj - sb) + kk;
+    eoff[j] = slotA[j] ? 256 * (iA0 + pj) + kk : (frB - frA) * fstride + 256 * (pj - sb) + kk;
   }
   // rows whose frame is further than 2^31 samples from the first one take the general path
-  const bool near = ((long long)(frB - frA) * fl < (1LL << 30)) && ((long long)(frB - frA) * fl > -(1LL << 30));
+  const bool near = ((long long)(frB - frA) * fstride < (1LL << 30)) && ((long long)(frB - frA) * fstride > -(1LL << 30));
 
   const bool fast = interior && near;  // wave-uniform
   float2 stage[NLD];
@@ -376,9 +376,9 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
         const int l = t >> 2, j = t & 3;
         const int lag = slotA[j] ? la[l] : lb[l];
         const int n = (slotA[j] ? 256 * (iA0 + 4 * j + segq) : 256 * (4 * j + segq - sb)) + kk + lag + 16 * c;
-        const bool inr = (n > 0) && (n < fl);  // cc:205, sample 0 excluded
-        const long long fb = (long long)(slotA[j] ? frA : frB) * fl;
-        const float2 v = frames[fb + min(max(n, 0), fl - 1)];
+        const bool inr = (n > 0) && (n < np);  // cc:205, sample 0 excluded
+        const long long fb = (long long)(slotA[j] ? frA : frB) * fstride;
+        const float2 v = frames[fb + min(max(n, 0), np - 1)];
         stage[t] = inr ? v : make_float2(0.0f, 0.0f);
       }
     }
@@ -466,9 +466,9 @@ void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   dim3 blk(64 * K4G_WAVES);
-  if (NL == 5) launch_timed(c, ps, k4_group<5>, dim3(blocks), blk, 0, fr, c->fc.fl, B, grps, G, po);
-  else if (NL == 6) launch_timed(c, ps, k4_group<6>, dim3(blocks), blk, 0, fr, c->fc.fl, B, grps, G, po);
-  else launch_timed(c, ps, k4_group<8>, dim3(blocks), blk, 0, fr, c->fc.fl, B, grps, G, po);
+  if (NL == 5) launch_timed(c, ps, k4_group<5>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
+  else if (NL == 6) launch_timed(c, ps, k4_group<6>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
+  else launch_timed(c, ps, k4_group<8>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
 }
 
 // ---------------------------------------------------------------------------
@@ -484,7 +484,7 @@ void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_
 // accumulator is exactly k4_group's (cc:193-195, 206-207).
 template <int NL, int STEP>
 __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
-    const float2 *__restrict__ frames, int fl, int nframes, const dev_grp *__restrict__ grps,
+    const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_grp *__restrict__ grps,
     int G, float *__restrict__ p_out) {
   constexpr int PPW = 16;
   constexpr int W = (NL - 1) * STEP;       // extra samples beyond the first lag's window
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   const bool mineA = pr < sb;
   const int own_i = mineA ? iA0 + pr : pr - sb;
   const int own_nb = (mineA ? l0A : l0B) + 256 * own_i;
-  const bool interior = __all((own_nb > 0) && (own_nb + 255 + 16 * Q < fl)  /* the loader fetches whole slots */);
+  const bool interior = __all((own_nb > 0) && (own_nb + 255 + 16 * Q < np)  /* the loader fetches whole slots */);
 
   // ---- this lane's tone phasor step (binary64 angle, cc:173-189) ------------
   float cd, sd;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   for (int j = 0; j < 4; j++) {
     const int pj = 4 * j + segq;
     const bool sA = pj < sb;
-    fbase[j] = (long long)(sA ? frA : frB) * fl;
+    fbase[j] = (long long)(sA ? frA : frB) * fstride;
     nfirst[j] = (sA ? l0A + 256 * (iA0 + pj) : l0B + 256 * (pj - sb)) + kk;
     src[j] = frames + fbase[j] + nfirst[j];
   }
@@ -568,8 +568,8 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         const int n = nfirst[j] + 16 * sl;
-        const bool inr = (n > 0) && (n < fl);  // cc:205, sample 0 excluded
-        const float2 v = frames[fbase[j] + min(max(n, 0), fl - 1)];
+        const bool inr = (n > 0) && (n < np);  // cc:205, sample 0 excluded
+        const float2 v = frames[fbase[j] + min(max(n, 0), np - 1)];
         stage[j] = inr ? v : make_float2(0.0f, 0.0f);
       }
     }
@@ -703,8 +703,8 @@ void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_gr
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   dim3 blk(64 * K4G_WAVES);
-  if (r5) launch_timed(c, ps, (k4_ring<5, 16>), dim3(blocks), blk, 0, fr, c->fc.fl, B, grps, G, po);
-  else launch_timed(c, ps, (k4_ring<6, 8>), dim3(blocks), blk, 0, fr, c->fc.fl, B, grps, G, po);
+  if (r5) launch_timed(c, ps, (k4_ring<5, 16>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
+  else launch_timed(c, ps, (k4_ring<6, 8>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
 }
 
 
@@ -734,7 +734,7 @@ constexpr int K4F_PAIRS = 54;   // symbols per workgroup: 162 = 3 x 54
 
 template <int NF, int CH>   // CH = samples per staged chunk (16 or 32)
 __global__ __launch_bounds__(256) void k4_fstage(
-    const float2 *__restrict__ frames, int fl, int nframes, const dev_hyp *__restrict__ hyps,
+    const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_hyp *__restrict__ hyps,
     int nslots, float *__restrict__ p_out) {
   constexpr int K4F_ROWDW = 2 * CH + 4;   // dwords per staged row: CH samples x 8 B + 16 B pad (16-byte aligned)
   constexpr int NCH = 256 / CH;           // chunks per symbol
@@ -773,9 +773,9 @@ __global__ __launch_bounds__(256) void k4_fstage(
 
   // ---- loader: round r of a chunk = symbol SEGS r + tid/CH, sample tid%CH ----
   const int kk = tid % CH, seg = tid / CH;
-  const float2 *fb = frames + (long long)h0.frame * fl;
+  const float2 *fb = frames + (long long)h0.frame * fstride;
   const int nb0 = h0.lag + 256 * (part * K4F_PAIRS);
-  const bool interior = (nb0 > 0) && (nb0 + 256 * K4F_PAIRS < fl);          // workgroup-uniform
+  const bool interior = (nb0 > 0) && (nb0 + 256 * K4F_PAIRS < np);          // workgroup-uniform
   float2 stage[NR];
   int nrow[NR];
 #pragma unroll
@@ -788,8 +788,8 @@ __global__ __launch_bounds__(256) void k4_fstage(
 #pragma unroll
       for (int r = 0; r < NR; r++) {
         const int n = nrow[r] + CH * c;
-        const bool inr = (n > 0) && (n < fl);      // cc:205, sample 0 excluded
-        const float2 v = fb[min(max(n, 0), fl - 1)];
+        const bool inr = (n > 0) && (n < np);      // cc:205, sample 0 excluded
+        const float2 v = fb[min(max(n, 0), np - 1)];
         stage[r] = inr ? v : make_float2(0.0f, 0.0f);
       }
     }
@@ -905,7 +905,7 @@ void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_
   if (nslots <= 0) return;
   prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
   launch_timed(c, ps, (k4_fstage<5, K4F_CHUNK>), dim3(3u * (unsigned)nslots), dim3(256), 0,
-               (const float2 *)frames, c->fc.fl, B, hyps, nslots, (float *)p);
+               (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p);
 }
 
 }  // namespace uwspr
@@ -939,7 +939,7 @@ constexpr int K4GR_WAVES = 4;
 
 template <int NL>
 __global__ __launch_bounds__(64 * K4GR_WAVES) void k4_grid(
-    const float2 *__restrict__ frames, int fl, int nframes,
+    const float2 *__restrict__ frames, int fstride, int np, int nframes,
     const uwspr_candidate *__restrict__ centres, const int32_t *__restrict__ cframe,
     grid_args ga, float cf, float *__restrict__ p_out) {
   extern __shared__ __align__(16) float lds_dyn[];
@@ -961,14 +961,14 @@ __global__ __launch_bounds__(64 * K4GR_WAVES) void k4_grid(
 
   // ---- load the symbol windows (whole) ------------------------------------
   {
-    const float2 *fb = frames + (long long)frame * fl;
+    const float2 *fb = frames + (long long)frame * fstride;
     const int n0 = ce.shift + ga.dlag_min + 256 * i_first;
     const int tot = nwin * ga.wlen;
     for (int e = lane; e < tot; e += 64) {
       const int w = e / ga.wlen, r = e - w * ga.wlen;
       const int n = n0 + 256 * w + r;
-      const bool inr = (n > 0) && (n < fl);  // cc:205, sample 0 excluded
-      const float2 v = fb[min(max(n, 0), fl - 1)];
+      const bool inr = (n > 0) && (n < np);  // cc:205, sample 0 excluded
+      const float2 v = fb[min(max(n, 0), np - 1)];
       win[w * ga.wstride + r] = inr ? v : make_float2(0.0f, 0.0f);
     }
   }
@@ -1090,7 +1090,7 @@ static void launch_grid_t(uwspr_ctx *c, prof_scope &ps, const float2 *fr, int nf
   const int waves = (npairs + 15) / 16;
   dim3 grid((waves + wpw - 1) / wpw, ncentres);
   const size_t lds = (size_t)wpw * ga.wmax * ga.wstride * sizeof(float2);
-  launch_timed(c, ps, k4_grid<NL>, grid, dim3(64 * wpw), lds, fr, c->fc.fl, nframes, centres,
+  launch_timed(c, ps, k4_grid<NL>, grid, dim3(64 * wpw), lds, fr, c->fstride, c->np, nframes, centres,
                      cframe, ga, (float)c->p.cf, po);
 }
 

@@ -106,7 +106,7 @@ static __device__ float k6_slm_drift_t0(double V1, double V2, int p1, int p2, fl
 }
 
 struct k6_args {
-  const float2 *frames; int fl; int nframes;
+  const float2 *frames; int fstride; int np; int nframes;
   const uwspr_candidate *cands; const int32_t *npk; int cand_stride; int per_frame; int nslots;
   float cf; int reuse;
   int njig;                     // mode-2 tries to produce: 17, or fewer (lazy S5)
@@ -162,7 +162,7 @@ __host__ __device__ constexpr int nth_bit(int n) {
 
 // bit h of `mask` = hypothesis h is computed; tq0 = table of a lag sweep (LAGS); S1/S4 use table h.
 template <int KIND, bool TAB>
-__device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int fl, int L0, int nrows,
+__device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int np, int L0, int nrows,
                                      int nchunks, uint32_t mask, int tq0, float fc, float fstep,
                                      float drp, float drm, int m_type, float slmc,
                                      const float *tabset, lds_f *stage) {
@@ -177,13 +177,13 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int fl, int 
   // counts as an LDS access too and would tie every LDS / scalar wait to HBM latency)
   const K6_GLOBAL v2f *fbg = (const K6_GLOBAL v2f *)uni_ptr(fb);
   tabset = uni_ptr(tabset);
-  fl = uni(fl); L0 = uni(L0); nrows = uni(nrows); nchunks = uni(nchunks); mask = (uint32_t)uni((int)mask);
+  np = uni(np); L0 = uni(L0); nrows = uni(nrows); nchunks = uni(nchunks); mask = (uint32_t)uni((int)mask);
   tq0 = uni(tq0); m_type = uni(m_type);
 
   // ---- loader: element e = tid + 1024 n -> row tid / 16 + 64 n, sample tid % 16
   const int lr = tid >> 4, lj = tid & 15;
   const int sbase = lr * K6_ROWDW + 2 * lj;
-  const bool interior = (L0 > 0) && (L0 + 256 * (nrows - 1) + 16 * nchunks < fl);   // workgroup-uniform
+  const bool interior = (L0 > 0) && (L0 + 256 * (nrows - 1) + 16 * nchunks < np);   // workgroup-uniform
   float2 greg[3];
   auto gload = [&](int c) {
     if (interior) {
@@ -198,8 +198,8 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int fl, int 
       for (int n = 0; n < 3; n++) {
         const int r = min(lr + 64 * n, nrows - 1);
         const int ns = L0 + 256 * r + lj + 16 * c;
-        const bool inr = (ns > 0) && (ns < fl);                 // cc:205, sample 0 excluded
-        const v2f v = fbg[min(max(ns, 0), fl - 1)];
+        const bool inr = (ns > 0) && (ns < np);                 // cc:205, sample 0 excluded
+        const v2f v = fbg[min(max(ns, 0), np - 1)];
         greg[n] = inr ? make_float2(v.x, v.y) : make_float2(0.0f, 0.0f);
       }
     }
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
       if (a.stamps && tid == 0) a.stamps[(size_t)slot * 64 + k] = wall_clock64();
     };
     stamp(0);
-    const float2 *fb = a.frames + (size_t)st.frame * a.fl;
+    const float2 *fb = a.frames + (size_t)st.frame * a.fstride;
     const int m_type = uni(st.m_type);
     const float slmc = st.slmc;
 
@@ -563,11 +563,11 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
       const float f0v = st.f1 + (float)0 * 0.0f;
       const int L0 = st.shift1 - 128;
       if (tabled) {
-        k6_pass<K6_S0, true>(fb, a.fl, L0, K6_MAXROWS, 28, 0x0fu, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc,
+        k6_pass<K6_S0, true>(fb, a.np, L0, K6_MAXROWS, 28, 0x0fu, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc,
                              launder(tabA), (lds_f *)stage);
         fold_plain(5, 0x0fu, 4);
       } else {
-        k6_pass<K6_S0, false>(fb, a.fl, L0, UWSPR_NSYM, 32, 0x1fu, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc,
+        k6_pass<K6_S0, false>(fb, a.np, L0, UWSPR_NSYM, 32, 0x1fu, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc,
                               tabA, (lds_f *)stage);
         fold_plain(5, 0x1fu, -1);
       }
@@ -596,8 +596,8 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
 #pragma unroll
       for (int q = 0; q < 5; q++) f0[q] = fc + (float)(q - 2) * 0.25f;
       const int L0 = st.shift1;
-      if (tabs_ok) k6_pass<K6_S1, true>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.25f, st.drift1, 0.0f, m_type, slmc, launder(tabA), (lds_f *)stage);
-      else k6_pass<K6_S1, false>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.25f, st.drift1, 0.0f, m_type, slmc, tabA, (lds_f *)stage);
+      if (tabs_ok) k6_pass<K6_S1, true>(fb, a.np, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.25f, st.drift1, 0.0f, m_type, slmc, launder(tabA), (lds_f *)stage);
+      else k6_pass<K6_S1, false>(fb, a.np, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.25f, st.drift1, 0.0f, m_type, slmc, tabA, (lds_f *)stage);
       stamp(10);
       fold_plain(5, mask, -1);
       stamp(11);
@@ -621,7 +621,7 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
     // =========================== S2 (cc:423-441): linear only, drift1 +- 0.5 at (f1, shift1)
     if (m_type == UWSPR_LINEAR) {
       const float f0v = st.f1 + (float)0 * 0.0f;
-      k6_pass<K6_S2, false>(fb, a.fl, st.shift1, UWSPR_NSYM, 16, 0x3u, 0, f0v, 0.0f, st.driftp, st.driftm, m_type, slmc, tabA, (lds_f *)stage);
+      k6_pass<K6_S2, false>(fb, a.np, st.shift1, UWSPR_NSYM, 16, 0x3u, 0, f0v, 0.0f, st.driftp, st.driftm, m_type, slmc, tabA, (lds_f *)stage);
       fold_plain(2, 0x3u, -1);
       if (tid == 0) {   // sched_step_body<3>, first half (cc:434-441)
         float syncp = -1e30f, syncm = -1e30f;
@@ -655,8 +655,8 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
         const float f0v = st.f1 + (float)0 * 0.0f;
         const int L0 = st.shift1 - 32;
         const uint32_t mask = st.cknown ? 0x1bu : 0x1fu;
-        if (tabled) k6_pass<K6_S3, true>(fb, a.fl, L0, UWSPR_NSYM, 20, mask, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc, launder(tabB), (lds_f *)stage);
-        else k6_pass<K6_S3, false>(fb, a.fl, L0, UWSPR_NSYM, 20, mask, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc, tabB, (lds_f *)stage);
+        if (tabled) k6_pass<K6_S3, true>(fb, a.np, L0, UWSPR_NSYM, 20, mask, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc, launder(tabB), (lds_f *)stage);
+        else k6_pass<K6_S3, false>(fb, a.np, L0, UWSPR_NSYM, 20, mask, 2, f0v, 0.0f, st.drift1, 0.0f, m_type, slmc, tabB, (lds_f *)stage);
         fold_plain(5, mask, -1);
         if (tid == 0) {   // sched_step_body<4>
           float bs = -1e30f; int bshift = 0; float bf = 0.0f; int bq = -1;
@@ -681,8 +681,8 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
 #pragma unroll
         for (int q = 0; q < 5; q++) f0[q] = fc + (float)(q - 2) * 0.05f;
         const int L0 = st.shift1;
-        if (tabs_ok) k6_pass<K6_S4, true>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.05f, st.drift1, 0.0f, m_type, slmc, launder(tabB), (lds_f *)stage);
-        else k6_pass<K6_S4, false>(fb, a.fl, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.05f, st.drift1, 0.0f, m_type, slmc, tabB, (lds_f *)stage);
+        if (tabs_ok) k6_pass<K6_S4, true>(fb, a.np, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.05f, st.drift1, 0.0f, m_type, slmc, launder(tabB), (lds_f *)stage);
+        else k6_pass<K6_S4, false>(fb, a.np, L0, UWSPR_NSYM, 16, mask, 0, fc, 0.05f, st.drift1, 0.0f, m_type, slmc, tabB, (lds_f *)stage);
         fold_plain(5, mask, -1);
         if (tid == 0) {   // sched_step_body<5>
           float bs = -1e30f; int bshift = 0; float bf = 0.0f; int bq = -1;
@@ -711,8 +711,8 @@ __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
         if (st.cknown) mask &= ~1u;   // try 0 repeats the S4 winner: its magnitudes are in pw
         const int L0 = st.shift1 - 64;
         if (mask) {
-          if (tab5) k6_pass<K6_S5, true>(fb, a.fl, L0, UWSPR_NSYM, 24, mask, wq, st.f1, 0.0f, st.drift1, 0.0f, m_type, slmc, launder(tabB), (lds_f *)stage);
-          else k6_pass<K6_S5, false>(fb, a.fl, L0, UWSPR_NSYM, 24, mask, 0, st.f1, 0.0f, st.drift1, 0.0f, m_type, slmc, tabB, (lds_f *)stage);
+          if (tab5) k6_pass<K6_S5, true>(fb, a.np, L0, UWSPR_NSYM, 24, mask, wq, st.f1, 0.0f, st.drift1, 0.0f, m_type, slmc, launder(tabB), (lds_f *)stage);
+          else k6_pass<K6_S5, false>(fb, a.np, L0, UWSPR_NSYM, 24, mask, 0, st.f1, 0.0f, st.drift1, 0.0f, m_type, slmc, tabB, (lds_f *)stage);
         }
         stamp(8);
         for (int base = 0; base < UWSPR_NJIG; base += K6_FOLDH) {
@@ -762,11 +762,14 @@ void launch_sched_fused(uwspr_ctx *c, const float *frames, int B, const uwspr_ca
   if (nslots <= 0) return;
   prof_scope ps(c, UWSPR_K_TONECORR, (int64_t)nslots * 35, true);
   k6_args a;
-  a.frames = (const float2 *)frames; a.fl = c->fc.fl; a.nframes = B;
+  a.frames = (const float2 *)frames; a.fstride = c->fstride; a.np = c->np; a.nframes = B;
   a.cands = cands; a.npk = npk; a.cand_stride = cand_stride; a.per_frame = per_frame; a.nslots = nslots;
   a.cf = (float)c->p.cf; a.reuse = c->reuse_centre ? 1 : 0;
   a.njig = njig;
-  a.tabs = c->d_tabs; a.counter = c->d_counter; a.out = out; a.state = c->d_state; a.pwin = c->d_pwin; a.resume = resume;
+  a.tabs = c->d_tabs; a.counter = c->d_counter; a.out = out; a.state = c->d_state; a.resume = resume;
+  // the winner's magnitudes are kept only for a lazy pass (run_schedule sized d_pwin for THIS batch) and
+  // read only by a resume pass: an eager pass must not write a buffer sized for an earlier, smaller batch
+  a.pwin = (njig < UWSPR_NJIG || resume) ? c->d_pwin : nullptr;
   a.stamps = c->d_sched_stamps;
   const int grid = nslots < c->sched_grid ? nslots : c->sched_grid;
   (void)hipMemsetAsync(c->d_counter, 0, sizeof(int), c->stream);

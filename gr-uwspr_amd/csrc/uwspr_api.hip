@@ -111,18 +111,19 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->use_lag_ring = !(getenv("UWSPR_K4_RING") && atoi(getenv("UWSPR_K4_RING")) == 0);
   c->use_fstage = !(getenv("UWSPR_K4_FSTAGE") && atoi(getenv("UWSPR_K4_FSTAGE")) == 0);
   c->reuse_centre = !(getenv("UWSPR_K4_REUSE") && atoi(getenv("UWSPR_K4_REUSE")) == 0);
-  // frequency/drift stages through the grid form: parity-tested but measured 9 % SLOWER than the
-  // flat kernel at 5 hypotheses per candidate (4 waves/SIMD, window loads not overlapped): opt-in
   c->use_fused = !(getenv("UWSPR_SCHED_FUSED") && atoi(getenv("UWSPR_SCHED_FUSED")) == 0);
   c->sched_nopad = getenv("UWSPR_SCHED_NOPAD") && atoi(getenv("UWSPR_SCHED_NOPAD")) != 0;
+  // frequency/drift stages through the grid form: parity-tested but measured 9 % SLOWER than the
+  // flat kernel at 5 hypotheses per candidate (4 waves/SIMD, window loads not overlapped): opt-in
   c->use_stage_grid = getenv("UWSPR_K4_STAGE_GRID") && atoi(getenv("UWSPR_K4_STAGE_GRID")) != 0;
   c->cap_slab = 0; c->d_slab = nullptr;
   c->sched_grid = getenv("UWSPR_SCHED_GRID") ? atoi(getenv("UWSPR_SCHED_GRID")) : 0;
   c->cap_tmpc = 0; c->d_tmpc = nullptr; c->cap_tmpn = 0; c->d_tmpn = nullptr;
   c->h_pin = nullptr; c->pin_busy[0] = c->pin_busy[1] = false;
-  c->d_stream[0] = c->d_stream[1] = nullptr; c->d_stream_frames = nullptr; c->st_hop = 0; c->st_maxf = 0; c->st_cap = 0; c->st_have = 0; c->st_cur = 0; c->st_pos = 0;
+  c->d_stream_frames = nullptr; c->cap_stream_frames = 0; c->ring_ev = nullptr;
+  c->fstride = p->fl; c->np = p->fl < 45000 ? p->fl : 45000;   // sync_and_demodulate_impl.cc:92
   c->ntries = UWSPR_NJIG; c->cap_pwin = 0; c->d_pwin = nullptr; c->cap_need = 0; c->d_need = nullptr;
-  c->last_slots = 0; c->last_sched_B = 0; c->last_sched_per_frame = 0;
+  c->last_slots = 0; c->last_sched_B = 0; c->last_sched_per_frame = 0; c->last_sched_lazy = false; c->last_sched_out = nullptr;
   c->cap_tabs = 0; c->d_tabs = nullptr; c->d_counter = nullptr; c->d_sched_stamps = nullptr; c->cap_sched_stamps = 0;
   *out = c;  // handed back even on failure so uwspr_last_error() can be read
 
@@ -274,8 +275,10 @@ extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
   void *bufs[] = {c->d_window, c->d_twiddle, c->d_k3_tile, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
                   c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_cent,
-                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter, c->d_sched_stamps, c->d_pwin, c->d_need, c->d_stream[0], c->d_stream[1], c->d_stream_frames, c->d_tmpc, c->d_tmpn};
+                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter, c->d_sched_stamps, c->d_pwin, c->d_need, c->d_stream_frames, c->d_tmpc, c->d_tmpn};
   for (void *b : bufs) if (b) (void)hipFree(b);
+  c->ring.close();
+  if (c->ring_ev) (void)hipEventDestroy(c->ring_ev);
   if (c->h_pin) { (void)hipHostFree(c->h_pin); (void)hipEventDestroy(c->pin_ev[0]); (void)hipEventDestroy(c->pin_ev[1]); }
   for (auto &e : c->prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -383,7 +386,8 @@ static int frames_on_device(uwspr_ctx *c, const float *frames, int B, int where,
   if (!frames || B <= 0) return fail(c, UWSPR_ERR_ARG, "frames=%p B=%d", (const void *)frames, B);
   if (where == UWSPR_DEVICE || where == UWSPR_DEVICE_FRAMES) { *dev = frames; return UWSPR_OK; }
   if (where != UWSPR_HOST) return fail(c, UWSPR_ERR_ARG, "where=%d", where);
-  const size_t bytes = (size_t)B * c->fc.fl * 2 * sizeof(float);
+  // frame b starts at frames + 2 * fstride * b: what is uploaded is the span the B frames cover
+  const size_t bytes = ((size_t)(B - 1) * c->fstride + c->fc.fl) * 2 * sizeof(float);
   size_t cap = c->cap_frames_bytes / sizeof(float);
   int rc = ensure(c, &c->d_frames, &cap, bytes / sizeof(float));
   c->cap_frames_bytes = cap * sizeof(float);
@@ -553,6 +557,7 @@ extern "C" int uwspr_sync_sweep(uwspr_ctx *c, const float *frames, int B, const 
   int rc = ready(c);
   if (rc) return rc;
   if (!hyps || H <= 0) return fail(c, UWSPR_ERR_ARG, "hyps=%p H=%d", (const void *)hyps, H);
+  if (where == UWSPR_DEVICE_FRAMES) return fail(c, UWSPR_ERR_ARG, "uwspr_sync_sweep: where is UWSPR_HOST or UWSPR_DEVICE");
   const float *d;
   if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
   if ((rc = ensure(c, &c->d_hyps, &c->cap_hyps, (size_t)H))) return rc;
@@ -584,6 +589,7 @@ extern "C" int uwspr_sync_grid(uwspr_ctx *c, const float *frames, int B, int whe
   if (rc) return rc;
   if (!centres || !df || !ddrift || !dlag || nf < 1 || ndrift < 1 || nlag < 1 || nf > 32 || ndrift > 32 || nlag > 4096)
     return fail(c, UWSPR_ERR_ARG, "uwspr_sync_grid: nf=%d ndrift=%d nlag=%d (nf, ndrift <= 32)", nf, ndrift, nlag);
+  if (where == UWSPR_DEVICE_FRAMES) return fail(c, UWSPR_ERR_ARG, "uwspr_sync_grid: where is UWSPR_HOST or UWSPR_DEVICE");
   const float *d;
   if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
   const long long H = (long long)B * nf * ndrift * nlag;
@@ -688,9 +694,26 @@ extern "C" int uwspr_sync_and_demodulate_batch(uwspr_ctx *c, const float *frames
 }
 
 // ------------------------------------------------------ refinement schedule
+static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uwspr_candidate *dcands,
+                             const int32_t *dnpk, int cand_stride, int per_frame, uwspr_demod_out *user_out);
+
+// What uwspr_demod_resume may continue is recorded here: the batch shape, whether the pass was lazy
+// (only then were the winner's magnitudes kept) and where its records went.  A failed call leaves
+// nothing to resume.
 static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_candidate *dcands,
                         const int32_t *dnpk, int cand_stride, int per_frame,
                         uwspr_demod_out *user_out = nullptr) {
+  c->last_sched_B = 0; c->last_sched_per_frame = 0; c->last_sched_lazy = false; c->last_sched_out = nullptr;
+  const int rc = run_schedule_impl(c, dframes, B, dcands, dnpk, cand_stride, per_frame, user_out);
+  if (rc) return rc;
+  c->last_slots = B * per_frame; c->last_sched_B = B; c->last_sched_per_frame = per_frame;
+  c->last_sched_lazy = c->ntries < UWSPR_NJIG;
+  c->last_sched_out = c->cur_dout;
+  return UWSPR_OK;
+}
+
+static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uwspr_candidate *dcands,
+                             const int32_t *dnpk, int cand_stride, int per_frame, uwspr_demod_out *user_out) {
   static const int hpc[6] = {5, 5, 2, 5, 5, UWSPR_NJIG};
   const size_t nslots = (size_t)B * per_frame;
   int rc;
@@ -712,7 +735,6 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
     }
     launch_sched_fused(c, dframes, B, dcands, dnpk, cand_stride, per_frame, c->cur_dout,
                        c->ntries < UWSPR_NJIG ? c->ntries : UWSPR_NJIG);
-    c->last_slots = (int)nslots; c->last_sched_B = B; c->last_sched_per_frame = per_frame;
     HIPCHK(c, hipGetLastError());
     return UWSPR_OK;
   }
@@ -762,7 +784,6 @@ static int run_schedule(uwspr_ctx *c, const float *dframes, int B, const uwspr_c
                                    UWSPR_NSYM * 16, nslots, hipMemcpyDeviceToDevice, c->stream));
     }
   }
-  c->last_slots = (int)nslots; c->last_sched_B = B; c->last_sched_per_frame = per_frame;
   HIPCHK(c, hipGetLastError());
   return UWSPR_OK;
 }
@@ -788,6 +809,7 @@ extern "C" int uwspr_demod_batch(uwspr_ctx *c, const float *frames, int B, int w
   }
   rc = run_schedule(c, d, B, dc, dn, cand_stride, max_per_frame);
   if (!rc) rc = copy_out(c, out, c->d_dout, (size_t)B * max_per_frame * sizeof(uwspr_demod_out), host_recs ? UWSPR_HOST : UWSPR_DEVICE);
+  if (!rc && !host_recs) c->last_sched_out = out;   // a device caller's copy of the records is what a device resume patches
   if (host_recs) (void)hipStreamSynchronize(c->stream);
   // uwspr_pack_slabs works on the buffers of a uwspr_pipeline_batch call only
   c->last_per_frame = 0;
@@ -819,10 +841,18 @@ extern "C" int uwspr_pipeline_batch(uwspr_ctx *c, const float *frames, int B, in
 
 // ------------------------------------------------- overlap-aware stream ingest
 // frame f = stream samples [f hop, f hop + fl): overlapping source rows (no memcpy2D form), contiguous destination
-__global__ void k_cut_frames(const float2 *__restrict__ src, float2 *__restrict__ dst, int hop, int fl) {
-  const int f = blockIdx.y;
+__global__ void k_cut_frames(const float2 *__restrict__ src, float2 *__restrict__ dst, int hop, int fl, int f0) {
+  const int f = f0 + blockIdx.y;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < fl; i += gridDim.x * blockDim.x)
     dst[(size_t)f * fl + i] = src[(size_t)f * hop + i];
+}
+
+extern "C" int uwspr_set_frame_stride(uwspr_ctx *c, int stride) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (stride < 0) return fail(c, UWSPR_ERR_ARG, "stride=%d", stride);
+  c->fstride = stride > 0 ? stride : c->fc.fl;
+  return UWSPR_OK;
 }
 
 extern "C" int uwspr_stream_open(uwspr_ctx *c, int hop, int max_frames) {
@@ -830,57 +860,84 @@ extern "C" int uwspr_stream_open(uwspr_ctx *c, int hop, int max_frames) {
   if (rc) return rc;
   if (hop <= 0 || hop > c->fc.fl || max_frames <= 0) return fail(c, UWSPR_ERR_ARG, "hop=%d max_frames=%d", hop, max_frames);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  for (int k = 0; k < 2; k++) if (c->d_stream[k]) { (void)hipFree(c->d_stream[k]); c->d_stream[k] = nullptr; }
-  if (c->d_stream_frames) { (void)hipFree(c->d_stream_frames); c->d_stream_frames = nullptr; }
-  c->st_hop = hop; c->st_maxf = max_frames;
-  c->st_cap = (size_t)(2 * max_frames) * hop + c->fc.fl;     // samples: a full take plus as much again
-  for (int k = 0; k < 2; k++) HIPCHK(c, hipMalloc((void **)&c->d_stream[k], c->st_cap * 2 * sizeof(float)));
-  HIPCHK(c, hipMalloc((void **)&c->d_stream_frames, (size_t)max_frames * c->fc.fl * 2 * sizeof(float)));
-  c->st_cur = 0; c->st_have = 0; c->st_pos = 0;
+  if (!c->ring.open(c->fc.fl, hop, max_frames))
+    return fail(c, UWSPR_ERR_NOMEM, "stream buffers (%d frames, hop %d): %s", max_frames, hop, hipGetErrorString(c->ring.err));
+  if (!c->ring_ev) HIPCHK(c, hipEventCreateWithFlags(&c->ring_ev, hipEventDisableTiming));
   return UWSPR_OK;
-}
-
-static int stream_ready(const uwspr_ctx *c) {
-  if (c->st_have < (size_t)c->fc.fl) return 0;
-  const size_t n = (c->st_have - c->fc.fl) / c->st_hop + 1;
-  return (int)(n < (size_t)c->st_maxf ? n : (size_t)c->st_maxf);
 }
 
 extern "C" int uwspr_stream_push(uwspr_ctx *c, const float *iq, int nsamples, int where, int *nready) {
   int rc = ready(c);
   if (rc) return rc;
-  if (!c->d_stream[0]) return fail(c, UWSPR_ERR_ARG, "uwspr_stream_push before uwspr_stream_open");
+  stream_ring &r = c->ring;
+  if (!r.is_open()) return fail(c, UWSPR_ERR_ARG, "uwspr_stream_push before uwspr_stream_open");
   if (nsamples < 0 || (nsamples > 0 && !iq)) return fail(c, UWSPR_ERR_ARG, "iq/nsamples");
-  if (c->st_have + (size_t)nsamples > c->st_cap)
-    return fail(c, UWSPR_ERR_ARG, "stream buffer full (%zu + %d > %zu samples): take frames first", c->st_have, nsamples, c->st_cap);
-  float *dst = c->d_stream[c->st_cur] + c->st_have * 2;
-  const size_t bytes = (size_t)nsamples * 2 * sizeof(float);
+  if (where != UWSPR_HOST && where != UWSPR_DEVICE && where != UWSPR_HOST_ASYNC) return fail(c, UWSPR_ERR_ARG, "where=%d", where);
+  if (r.have + (size_t)nsamples > r.cap)
+    return fail(c, UWSPR_ERR_ARG, "stream buffer full (%zu + %d > %zu samples): take frames first", r.have, nsamples, r.cap);
   if (nsamples > 0) {
-    if (where == UWSPR_HOST) { if ((rc = upload(c, dst, iq, bytes))) return rc; }
-    else HIPCHK(c, hipMemcpyAsync(dst, iq, bytes, hipMemcpyDeviceToDevice, c->stream));
+    bool ok;
+    if (where == UWSPR_DEVICE) {   // produced by work on the context's stream
+      HIPCHK(c, hipEventRecord(c->ring_ev, c->stream));
+      ok = r.append(iq, (size_t)nsamples, true, c->ring_ev);
+    } else {
+      ok = r.append(iq, (size_t)nsamples, false);
+      // The upload is a DMA on the ring's copy stream.  A pageable source has been staged and is free
+      // again; a page-locked one is read by the DMA itself, so UWSPR_HOST waits for it (the copy stream
+      // carries nothing but uploads: this is the transfer time, not a wait for the search kernels) and
+      // UWSPR_HOST_ASYNC leaves that to uwspr_stream_wait_uploads.
+      if (ok && where == UWSPR_HOST && r.last_direct) ok = r.wait_uploads();
+    }
+    if (!ok) return fail(c, UWSPR_ERR_HIP, "stream upload: %s", hipGetErrorString(r.err));
   }
-  c->st_have += nsamples;
-  if (nready) *nready = stream_ready(c);
+  if (nready) *nready = r.ready();
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_stream_wait_uploads(uwspr_ctx *c) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (c->ring.is_open() && !c->ring.wait_uploads()) return fail(c, UWSPR_ERR_HIP, "stream upload: %s", hipGetErrorString(c->ring.err));
+  return UWSPR_OK;
+}
+
+// the next k frames in place on the context's stream (shared by the two take forms)
+static int stream_view(uwspr_ctx *c, int nframes, const float **view, long long *first_pos) {
+  stream_ring &r = c->ring;
+  if (!r.is_open() || nframes <= 0 || nframes > r.ready())
+    return fail(c, UWSPR_ERR_ARG, "uwspr_stream_take(%d): %d frames are complete", nframes, r.is_open() ? r.ready() : 0);
+  // whatever read earlier views has been enqueued on the stream by now (a view is valid until the next take)
+  HIPCHK(c, hipEventRecord(c->ring_ev, c->stream));
+  r.reader_done(0, c->ring_ev); r.reader_done(1, c->ring_ev);
+  if (!r.view(nframes, c->stream, view, first_pos, nullptr)) return fail(c, UWSPR_ERR_HIP, "stream view: %s", hipGetErrorString(r.err));
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_stream_take_view(uwspr_ctx *c, int nframes, const float **frames, int *stride, long long *first_pos) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (!frames) return fail(c, UWSPR_ERR_ARG, "frames");
+  if ((rc = stream_view(c, nframes, frames, first_pos))) return rc;
+  if (stride) *stride = c->ring.hop;
   return UWSPR_OK;
 }
 
 extern "C" int uwspr_stream_take(uwspr_ctx *c, int nframes, float *dev_dst, const float **frames, long long *first_pos) {
   int rc = ready(c);
   if (rc) return rc;
-  if (!c->d_stream[0] || nframes <= 0 || nframes > stream_ready(c))
-    return fail(c, UWSPR_ERR_ARG, "uwspr_stream_take(%d): %d frames are complete", nframes, c->d_stream[0] ? stream_ready(c) : 0);
-  float *dst = dev_dst ? dev_dst : c->d_stream_frames;
-  const float *src = c->d_stream[c->st_cur];
-  hipLaunchKernelGGL(k_cut_frames, dim3(44, nframes), dim3(256), 0, c->stream, (const float2 *)src, (float2 *)dst,
-                     c->st_hop, c->fc.fl);
+  const float *src = nullptr;
+  if ((rc = stream_view(c, nframes, &src, first_pos))) return rc;
+  float *dst = dev_dst;
+  if (!dst) {
+    if ((rc = ensure(c, &c->d_stream_frames, &c->cap_stream_frames, (size_t)c->ring.maxf * c->fc.fl * 2))) return rc;
+    dst = c->d_stream_frames;
+  }
+  for (int f0 = 0; f0 < nframes; f0 += 32768) {
+    const int nf = std::min(32768, nframes - f0);
+    hipLaunchKernelGGL(k_cut_frames, dim3(44, nf), dim3(256), 0, c->stream, (const float2 *)src, (float2 *)dst,
+                       c->ring.hop, c->fc.fl, f0);
+  }
   HIPCHK(c, hipGetLastError());
-  // what later frames still need moves to the front of the other buffer
-  const size_t used = (size_t)nframes * c->st_hop, rest = c->st_have - used;
-  if (rest) HIPCHK(c, hipMemcpyAsync(c->d_stream[c->st_cur ^ 1], src + used * 2, rest * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
-  c->st_cur ^= 1;
-  c->st_have = rest;
-  if (first_pos) *first_pos = c->st_pos;
-  c->st_pos += (long long)used;
   if (frames) *frames = dst;
   return UWSPR_OK;
 }
@@ -888,7 +945,7 @@ extern "C" int uwspr_stream_take(uwspr_ctx *c, int nframes, float *dev_dst, cons
 extern "C" int uwspr_stream_reset(uwspr_ctx *c, long long pos) {
   int rc = ready(c);
   if (rc) return rc;
-  c->st_have = 0; c->st_pos = pos;
+  c->ring.reset(pos);
   return UWSPR_OK;
 }
 
@@ -917,8 +974,13 @@ extern "C" int uwspr_demod_resume(uwspr_ctx *c, const float *frames, int B, int 
   int rc = ready(c);
   if (rc) return rc;
   if (!need || !out || B <= 0 || max_per_frame <= 0) return fail(c, UWSPR_ERR_ARG, "need/out/B/max_per_frame");
-  if (!c->d_pwin || c->last_sched_B != B || c->last_sched_per_frame != max_per_frame)
+  if (!c->d_pwin || !c->last_sched_lazy || c->last_sched_B != B || c->last_sched_per_frame != max_per_frame)
     return fail(c, UWSPR_ERR_ARG, "uwspr_demod_resume follows a schedule call of the same batch made with uwspr_set_tries(< %d)", UWSPR_NJIG);
+  // the records of the first pass must be where this call patches them
+  if (where == UWSPR_DEVICE ? (out != c->last_sched_out) : (c->last_sched_out != c->d_dout))
+    return fail(c, UWSPR_ERR_ARG, "uwspr_demod_resume: the first pass wrote its records to %s; resume with %s",
+                c->last_sched_out == c->d_dout ? "the context (a host-record call)" : "the caller's device buffer",
+                c->last_sched_out == c->d_dout ? "where = UWSPR_HOST / UWSPR_DEVICE_FRAMES" : "where = UWSPR_DEVICE and that buffer");
   const float *d;
   if ((rc = frames_on_device(c, frames, B, where, &d))) return rc;
   const size_t nslots = (size_t)B * max_per_frame;

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/uwspr_hip.h"
+#include "stream_ring.h"
 
 namespace uwspr {
 
@@ -151,12 +152,18 @@ struct uwspr_ctx {
   size_t cap_tmpc; uwspr_candidate *d_tmpc; size_t cap_tmpn; int32_t *d_tmpn;   // uwspr_demod_batch: host records staged
   // pinned staging for host -> device copies (two halves, ping-pong)
   void *h_pin; hipEvent_t pin_ev[2]; bool pin_busy[2];
-  // overlap-aware stream ingest (uwspr_stream_*): the stream tail lives on the device
-  float *d_stream[2]; float *d_stream_frames; int st_hop, st_maxf, st_cur; size_t st_cap, st_have; long long st_pos;
+  // overlap-aware stream ingest (uwspr_stream_*): the stream tail lives on the device (stream_ring.h)
+  uwspr::stream_ring ring; float *d_stream_frames; size_t cap_stream_frames;
+  hipEvent_t ring_ev;                 // recorded on `stream` at every take: the readers of earlier views are behind it
+  // Frame pitch of the current calls (uwspr_set_frame_stride; default fl = contiguous frames) and the
+  // sample bound of the fine search: npoints = 45000 whatever fl is (sync_and_demodulate_impl.cc:92,
+  // passed at cc:413-465), capped at fl where the reference would read past its arrays.
+  int fstride, np;
   int ntries;                         // mode-2 tries per candidate a schedule call produces (uwspr_set_tries)
   size_t cap_pwin; float *d_pwin;     // [nslots][162][4] winner magnitudes kept for uwspr_demod_resume (ntries < 17)
   size_t cap_need; uint8_t *d_need;   // staging of the resume mask
   int last_slots, last_sched_B, last_sched_per_frame;
+  bool last_sched_lazy; uwspr_demod_out *last_sched_out;   // what uwspr_demod_resume may continue (run_schedule)
   unsigned long long *d_sched_stamps; size_t cap_sched_stamps;   // UWSPR_SCHED_STAMPS=1: phase times of the last launch
   size_t cap_slab; uint8_t *d_slab;
 

@@ -28,7 +28,7 @@ HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
             "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 NSYM, NSLM, NK0, NIFR, NJIG = 162, 125, 26, 5, 17
-HOST, DEVICE, DEVICE_FRAMES = 0, 1, 2
+HOST, DEVICE, DEVICE_FRAMES, HOST_ASYNC = 0, 1, 2, 3
 LINEAR, NONLINEAR = 0, 1
 
 
@@ -143,7 +143,8 @@ class Prof(C.Structure):
 ABI_SYMBOLS = [
     "uwspr_ctx_create", "uwspr_ctx_destroy", "uwspr_last_error", "uwspr_status_string",
     "uwspr_get_info", "uwspr_set_stream", "uwspr_synchronize", "uwspr_frontend_batch",
-    "uwspr_frontend_taps", "uwspr_stream_open", "uwspr_stream_push", "uwspr_stream_take", "uwspr_stream_reset",
+    "uwspr_frontend_taps", "uwspr_set_frame_stride", "uwspr_stream_open", "uwspr_stream_push", "uwspr_stream_wait_uploads",
+    "uwspr_stream_take_view", "uwspr_stream_take", "uwspr_stream_reset",
     "uwspr_device_alloc", "uwspr_device_free", "uwspr_host_alloc", "uwspr_host_free", "uwspr_fdr_batch",
     "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
     "uwspr_sync_sweep", "uwspr_sync_grid", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
@@ -194,6 +195,9 @@ def lib():
     L.uwspr_stream_push.argtypes = [vp, vp, ip, ip, C.POINTER(C.c_int)]
     L.uwspr_stream_take.argtypes = [vp, ip, vp, C.POINTER(vp), C.POINTER(C.c_longlong)]
     L.uwspr_stream_reset.argtypes = [vp, C.c_longlong]
+    L.uwspr_set_frame_stride.argtypes = [vp, ip]
+    L.uwspr_stream_wait_uploads.argtypes = [vp]
+    L.uwspr_stream_take_view.argtypes = [vp, ip, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     L.uwspr_device_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.uwspr_device_free.argtypes = [vp]
     L.uwspr_device_free.restype = None

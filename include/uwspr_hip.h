@@ -13,7 +13,7 @@
  *   - `where` says whether the bulk pointers of that call are host
  *     (UWSPR_HOST) or device (UWSPR_DEVICE) memory; a call never mixes them.
  *   - frames are interleaved (I,Q) binary32 pairs, `fl` pairs per frame,
- *     frame b at frames + 2*fl*b: the payload of the PDU that
+ *     frame b at frames + 2*fl*b (or 2*stride*b, uwspr_set_frame_stride): the payload of the PDU that
  *     sliding_window_stream_to_pdu emits (lib/sliding_window_stream_to_pdu_impl.cc:113-135)
  *     narrowed from complex<double> to the gr_complex it was built from (cc:109).
  *   - a context is thread-compatible: one context per host thread; no globals.
@@ -43,7 +43,8 @@ typedef enum {
 
 /* UWSPR_DEVICE_FRAMES (uwspr_fdr_batch, uwspr_demod_batch, uwspr_pipeline_batch, uwspr_demod_resume): the frames are device
  * memory (e.g. what uwspr_stream_take returned), every other pointer of the call is host memory. */
-enum { UWSPR_HOST = 0, UWSPR_DEVICE = 1, UWSPR_DEVICE_FRAMES = 2 };
+enum { UWSPR_HOST = 0, UWSPR_DEVICE = 1, UWSPR_DEVICE_FRAMES = 2,
+       UWSPR_HOST_ASYNC = 3 /* uwspr_stream_push only: see there */ };
 enum { UWSPR_LINEAR = 0, UWSPR_NONLINEAR = 1 };   /* enum Modes, lib/candidate_t.h:36 */
 
 #define UWSPR_NSYM 162      /* symbols per frame */
@@ -160,18 +161,36 @@ int uwspr_frontend_taps(float *taps_re_im, int cap_pairs);
 /* sliding_window_stream_to_pdu::work (lib/sliding_window_stream_to_pdu_impl.cc:97-138) cuts the
  * 375 S/s stream into frames of fl samples that start every hop = shift*fs = 3375 samples: 41625 of
  * a frame's 45000 samples are its predecessor's.  Handing whole frames to the calls below uploads
- * every sample 13 times; through this interface every sample crosses PCIe ONCE and the frames are
- * cut on the device:
+ * every sample 13 times; through this interface every sample crosses PCIe ONCE, on a copy stream of
+ * its own (uploads overlap the search kernels of the batches before), and the frames are read where
+ * they lie:
  *   uwspr_stream_open(ctx, hop, max_frames)        hop in samples; at most max_frames per take
- *   uwspr_stream_push(ctx, iq, n, where, &nready)  append n (I,Q) pairs; nready = complete frames waiting
- *   uwspr_stream_take(ctx, k, dev_dst, &frames, &pos)  the next k frames as [k][fl] (I,Q) pairs in device
- *       memory (dev_dst, or NULL = a buffer of the context, valid until the next take); pos =
- *       stream index of the first one's first sample; consumes k*hop samples.  Use the result with
- *       where = UWSPR_DEVICE or UWSPR_DEVICE_FRAMES.
+ *   uwspr_stream_push(ctx, iq, n, where, &nready)  append n (I,Q) pairs; nready = complete frames waiting.
+ *       where = UWSPR_HOST: on return iq may be reused (pageable memory is staged; a page-locked buffer
+ *       is read by the DMA itself and the call waits for that transfer -- not for any kernel);
+ *       UWSPR_HOST_ASYNC: page-locked iq is only enqueued and must stay unmodified until
+ *       uwspr_stream_wait_uploads returns; UWSPR_DEVICE: iq is device memory written by work on the
+ *       context's stream.
+ *   uwspr_stream_take_view(ctx, k, &frames, &stride, &pos)   the next k frames IN PLACE: frame j starts
+ *       at frames + 2*stride*j floats (stride = hop; the frames overlap in memory as they do in the
+ *       stream), valid until the next take; pos = stream index of the first one's first sample;
+ *       consumes k*hop samples.  Use with uwspr_set_frame_stride(ctx, stride) and where = UWSPR_DEVICE
+ *       or UWSPR_DEVICE_FRAMES; the kernels reading them must be enqueued before the next take.
+ *   uwspr_stream_take(ctx, k, dev_dst, &frames, &pos)        the same frames COPIED out as contiguous
+ *       [k][fl] pairs (dev_dst, or NULL = a buffer of the context, valid until the next take) for
+ *       consumers that keep frames beyond the next take (the block mirror's FDR -> sync hand-over).
  *   uwspr_stream_reset(ctx, pos)                   drop what is buffered; the next sample pushed has index pos
- * Frame k of the stream is bit for bit the frame the reference's PDU k carries. */
+ * Frame k of the stream is bit for bit the frame the reference's PDU k carries.
+ *
+ * uwspr_set_frame_stride(ctx, s): the calls that follow read frame b of their `frames` argument at
+ * frames + 2*s*b floats instead of 2*fl*b (s = 0 restores fl).  With where = UWSPR_HOST the span
+ * (B-1)*s + fl is uploaded once, so a host buffer holding a stretch of the stream (s = hop) is also
+ * ingested without repeats.  Applies to every entry point that takes frames. */
+int uwspr_set_frame_stride(uwspr_ctx *ctx, int stride_samples);
 int uwspr_stream_open(uwspr_ctx *ctx, int hop, int max_frames);
 int uwspr_stream_push(uwspr_ctx *ctx, const float *iq, int nsamples, int where, int *nready);
+int uwspr_stream_wait_uploads(uwspr_ctx *ctx);
+int uwspr_stream_take_view(uwspr_ctx *ctx, int nframes, const float **frames, int *stride, long long *first_pos);
 int uwspr_stream_take(uwspr_ctx *ctx, int nframes, float *dev_dst, const float **frames, long long *first_pos);
 int uwspr_stream_reset(uwspr_ctx *ctx, long long pos);
 /* device memory for callers without a HIP runtime of their own (the block mirror's frame hand-over) */

@@ -227,10 +227,21 @@ def slm_instances():
     return out
 
 
+# sync_and_demodulate_impl.cc:92: `npoints = 45000`, the sample bound every call of the fine search is
+# given (cc:413-465) WHATEVER the frame length fl is: with fl > 45000 the samples from 45000 on are
+# ignored by the fine search (the spectrogram, FDR_impl.cc:118, still uses them).  With fl < 45000 the
+# reference would index past its fl-sized arrays (cc:340: `float idat[fl]`): defined here as np = fl.
+NPOINTS = 45000
+
+
+def npoints(nsamples):
+    return min(NPOINTS, int(nsamples))
+
+
 def sync_and_demodulate(cand, cf, iq, f1, ifmin, ifmax, fstep, shift1, lagmin, lagmax, lagstep,
                         drift1, symfac, mode, np_points=None):
-    """Argument-for-argument twin of sync_and_demodulate_impl.cc:126.
-    Returns (sync, shift1, f1, symbols[162])."""
+    """Argument-for-argument twin of sync_and_demodulate_impl.cc:126 (np_points = the `np` argument;
+    default: what demodulate() passes, cc:92).  Returns (sync, shift1, f1, symbols[162])."""
     iq = np.asarray(iq, dtype=np.float32).reshape(-1, 2)
     idat = np.ascontiguousarray(iq[:, 0])
     qdat = np.ascontiguousarray(iq[:, 1])
@@ -238,20 +249,21 @@ def sync_and_demodulate(cand, cf, iq, f1, ifmin, ifmax, fstep, shift1, lagmin, l
     symbols = np.zeros(NSYM, np.uint8)
     f1c, sh, dr, sy = C.c_float(f1), C.c_int(shift1), C.c_float(drift1), C.c_float(0)
     lib().orc_sync_and_demodulate(c.ctypes.data, cf, _fp(idat), _fp(qdat),
-                                  np_points or idat.size,
+                                  np_points or npoints(idat.size),
                                   symbols.ctypes.data_as(C.POINTER(C.c_ubyte)), C.byref(f1c),
                                   ifmin, ifmax, fstep, C.byref(sh), lagmin, lagmax, lagstep,
                                   C.byref(dr), symfac, C.byref(sy), mode)
     return sy.value, sh.value, f1c.value, symbols
 
 
-def demod_candidate(cand, cf, iq):
+def demod_candidate(cand, cf, iq, np_points=None):
+    """The per-candidate body of demodulate(), cc:403-482, with the reference's npoints (cc:92)."""
     iq = np.asarray(iq, dtype=np.float32).reshape(-1, 2)
     idat = np.ascontiguousarray(iq[:, 0])
     qdat = np.ascontiguousarray(iq[:, 1])
     c = np.array(cand, dtype=CAND_DTYPE).reshape(1).copy()
     out = DemodOut()
-    lib().orc_demod_candidate(c.ctypes.data, cf, _fp(idat), _fp(qdat), idat.size, C.byref(out))
+    lib().orc_demod_candidate(c.ctypes.data, cf, _fp(idat), _fp(qdat), np_points or npoints(idat.size), C.byref(out))
     return {
         "f1": out.f1, "drift1": out.drift1, "sync1": out.sync1, "shift1": out.shift1,
         "worth_a_try": out.worth_a_try,

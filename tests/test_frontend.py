@@ -96,3 +96,74 @@ def test_synthetic_audio_round_trip(G):
         assert dec is not None
         assert (np.unpackbits(dec[0].view(np.uint8))[:50] == meta[b]["bits"]).all()
         assert abs(float(out[b, 0]["f1"]) - meta[b]["f_off"]) < 0.2
+
+
+# ---- the reference's own closed-loop demo (README.md:61) ----------------------------------------
+def _closed_loop_audio(seconds=120):
+    """examples/WaveFilePlusNoiseDecode.grc: test_1500_Hz.wav x 0.1 (grc:802) + whales_12000sps.wav x 1
+    (grc:751), both sources repeating; wavfile_source scales int16 by 1/32768."""
+    rec = np.load(os.path.join(GOLDEN, "closed_loop_int16.npz"))
+    n = seconds * 12000
+    tx = np.resize(rec["tx"].astype(np.float64) / 32768.0, n)
+    wh = np.resize(rec["whales"].astype(np.float64) / 32768.0, n)
+    return (float(rec["tx_gain"]) * tx + float(rec["whales_gain"]) * wh).astype(np.float32)
+
+
+def _decode_set(G, recs):
+    out = set()
+    for r in recs:
+        dec = G.decode_candidate(r)
+        if dec is not None:
+            out.add(G.unpack_message(dec[0])[1])
+    return out
+
+
+def _oracle_records(G, oracle, frame, ncand):
+    recs = []
+    for c in oracle.FDR().transform(frame)[:ncand]:
+        d = oracle.demod_candidate(c, 1500, frame)
+        rec = np.zeros(1, G.native.DEMOD_DTYPE)[0]
+        for k in ("f1", "drift1", "sync1", "shift1", "worth_a_try", "jig_sync", "jig_rms", "jig_shift", "symbols"):
+            rec[k] = d[k]
+        recs.append(rec)
+    return recs
+
+
+def test_closed_loop_demo_decodes_on_the_cpu_oracle(G, oracle):
+    """The input the reference's authors demo (sender wav x 0.1 + whale noise) through the float64
+    restatement of the front-end formula, the oracle's FDR + schedule and the host tail:
+    `VE3EMB FN25 30` (README.md:37) -- a second reference-held known answer for the oracle, on a noisy
+    frame this time."""
+    x = _closed_loop_audio()
+    y = _ref_frontend(x, G.frontend_taps())
+    frame = np.stack([y.real, y.imag], axis=1).astype(np.float32)
+    assert _decode_set(G, _oracle_records(G, oracle, frame, 2)) == {"VE3EMB FN25 30"}
+
+
+@pytest.mark.gpu
+def test_closed_loop_demo_decodes_end_to_end_on_the_gpu(G, oracle):
+    """BASELINE configs[0]'s flowgraph input on the HIP path: wav mix -> K0 -> FDR -> schedule -> Fano
+    -> unpack = `VE3EMB FN25 30`; the set of messages decoded from the GPU's records equals the set
+    the CPU (oracle FDR + schedule on the same 375 S/s frame, same host tail) decodes, and every record
+    field equals the oracle's.  Also with the whale noise three times as loud."""
+    x = _closed_loop_audio()
+    rec = np.load(os.path.join(GOLDEN, "closed_loop_int16.npz"))
+    loud = (0.1 * rec["tx"].astype(np.float64) / 32768.0 +
+            3.0 * np.resize(rec["whales"].astype(np.float64) / 32768.0, x.size)).astype(np.float32)
+    ctx = G.Context()
+    try:
+        frames = ctx.frontend(np.stack([x, loud]))
+        cands, out = ctx.pipeline_batch(frames, max_per_frame=2)
+    finally:
+        ctx.close()
+    for b in range(2):
+        n = min(2, len(cands[b]))
+        gpu = _decode_set(G, [out[b, j] for j in range(n)])
+        orc = _oracle_records(G, oracle, frames[b], 2)
+        assert gpu == _decode_set(G, orc), b
+        for j in range(n):
+            assert int(out[b, j]["shift1"]) == int(orc[j]["shift1"]) and int(out[b, j]["worth_a_try"]) == int(orc[j]["worth_a_try"])
+            assert out[b, j]["symbols"].tobytes() == orc[j]["symbols"].tobytes(), (b, j)
+            assert np.float32(out[b, j]["sync1"]).tobytes() == np.float32(orc[j]["sync1"]).tobytes()
+        if b == 0:
+            assert gpu == {"VE3EMB FN25 30"}

@@ -585,11 +585,13 @@ def test_other_carrier_and_frame_parameters(G, oracle):
 
 @pytest.mark.parametrize("fl", [45056, 48000])
 def test_other_frame_lengths(G, oracle, fl):
-    """fl is a parameter of the reference's blocks (the row count of the spectrogram and the
-    sample bound np of the fine search follow it: FDR_impl.cc:118, sync_and_demodulate_impl.cc:205).
+    """fl is a parameter of the reference's blocks: the row count of the spectrogram follows it
+    (FDR_impl.cc:118), the sample bound of the fine search does NOT -- `npoints = 45000`
+    (sync_and_demodulate_impl.cc:92) is what every sync_and_demodulate() call gets as np (cc:413-465),
+    so with fl > 45000 the fine search ignores the samples from 45 000 on.
     Two frames longer than the flowgraph's 45 000 samples (a shorter one has fewer than the 348 rows the
     coarse search indexes: UWSPR_ERR_UNSUPPORTED; the reference reads out of bounds): spectrogram band,
-    candidates and the whole schedule against the oracle."""
+    candidates and the whole schedule against the oracle (which passes np = 45000 as the reference does)."""
     base = G.synth.make_frames(3, seed=424242, snr_db=-17.0)
     if fl <= base.shape[1]:
         fr = np.ascontiguousarray(base[:, :fl])
@@ -618,6 +620,100 @@ def test_other_frame_lengths(G, oracle, fl):
                     assert np.float32(o[k]).tobytes() == np.float32(d[k]).tobytes(), (fl, b, j, k)
                 if d["worth_a_try"]:
                     assert (o["symbols"] == d["symbols"]).all(), (fl, b, j)
+
+
+def _late_frames(G, fl, start, n=2, seed=515151, snr_db=-14.0):
+    """Frames of fl samples whose transmission starts at sample `start` (so that its last symbols lie
+    beyond sample 45 000), noise everywhere."""
+    base = G.synth.make_frames(n, seed=seed, snr_db=None)
+    sig = base[:, G.synth.START:G.synth.START + 162 * 256]
+    rng = np.random.default_rng(seed)
+    fr = (G.synth.sigma_for_snr(snr_db) * rng.standard_normal((n, fl, 2))).astype(np.float32)
+    fr[:, start:start + sig.shape[1]] += sig
+    return np.ascontiguousarray(fr)
+
+
+def test_fine_search_ignores_samples_from_45000_on(G, oracle):
+    """npoints = 45000 (sync_and_demodulate_impl.cc:92, the np of cc:205's `n < np`) with fl = 48 000 and
+    windows that reach past sample 45 000: a transmission starting at sample 5 000 ends at 46 472, so
+    its last six symbols are (partly) invisible to the fine search.  Through every path that takes a
+    lag -- the reference-signature calls (modes 0/1/2), the flat sweep, the grid sweep and the
+    schedule (both forms) with hand-made candidates at shift = 5 000 -- the GPU equals the oracle run
+    with np = 45 000 and DIFFERS from the oracle run with np = fl (the samples are there and are not
+    zero, so the test can tell the two apart)."""
+    import os
+    fl, start = 48000, 5000
+    fr = _late_frames(G, fl, start)
+    lin = np.zeros(1, oracle.CAND_DTYPE)[0]
+    # mode-2 metrics with np = 45000 / np = fl differ, or the test proves nothing
+    s45, _, _, y45 = oracle.sync_and_demodulate(lin, 1500, fr[0], 0.0, 0, 0, 0.0, start, 0, 0, 1, 0.0, 50, 2)
+    sfl, _, _, yfl = oracle.sync_and_demodulate(lin, 1500, fr[0], 0.0, 0, 0, 0.0, start, 0, 0, 1, 0.0, 50, 2,
+                                                np_points=fl)
+    assert np.float32(s45).tobytes() != np.float32(sfl).tobytes() and (y45 != yfl).any()
+
+    c = G.Context(fl=fl)
+    try:
+        # (1) the reference-signature call form, all three modes, lags around the late start
+        calls = np.zeros(6, G.native.CALL_DTYPE)
+        k = 0
+        for b in range(2):
+            for mode in (0, 1, 2):
+                q = calls[k]
+                q["frame"] = b; q["f1"] = 0.0; q["ifmin"] = -2; q["ifmax"] = 2; q["fstep"] = 0.25
+                q["shift1"] = start; q["lagmin"] = start - 128; q["lagmax"] = start + 128; q["lagstep"] = 64
+                q["drift1"] = 0.0; q["symfac"] = 50; q["mode"] = mode
+                k += 1
+        res = c.sync_and_demodulate(fr, calls)
+        for q, r in zip(calls, res):
+            s, sh, f1, y = oracle.sync_and_demodulate(lin, 1500, fr[int(q["frame"])], float(q["f1"]), int(q["ifmin"]),
+                                                      int(q["ifmax"]), float(q["fstep"]), int(q["shift1"]),
+                                                      int(q["lagmin"]), int(q["lagmax"]), int(q["lagstep"]),
+                                                      float(q["drift1"]), 50, int(q["mode"]))
+            assert np.float32(r["sync"]).tobytes() == np.float32(s).tobytes(), int(q["mode"])
+            assert int(r["shift1"]) == sh and np.float32(r["f1"]).tobytes() == np.float32(f1).tobytes()
+            if int(q["mode"]) == 2:
+                assert (r["symbols"] == y).all()
+        # (2) flat sweep and grid sweep around a centre at the late start
+        cent = np.zeros(2, G.native.CAND_DTYPE)
+        cent["shift"] = start
+        hy = G.sweep_grid(cent, [0, 1])
+        sync, sym = c.sync_sweep(fr, hy, soft=True)
+        for qi in range(0, len(hy), 37):
+            h = hy[qi]
+            s, _, _, y = oracle.sync_and_demodulate(lin, 1500, fr[int(h["frame"])], float(h["f0"]), 0, 0, 0.0,
+                                                    int(h["lag"]), 0, 0, 1, float(h["drift"]), 50, 2)
+            assert np.float32(sync[qi]).tobytes() == np.float32(s).tobytes() and (sym[qi] == y).all(), qi
+        from gr_uwspr_amd import sweep as SW
+        gs, gy = c.sync_grid(fr, cent, np.array(SW.DF_STEPS, np.float32) * np.float32(0.25),
+                             np.array(SW.DRIFTS, np.float32), np.array(SW.LAGS, np.int32))
+        flat = sync.reshape(2, 5, 8, 5).transpose(0, 1, 3, 2)      # flat order is (freq, lag, drift)
+        assert gs.reshape(2, 5, 5, 8).tobytes() == np.ascontiguousarray(flat).tobytes()
+        # (3) the schedule, both forms, from hand-made candidates at the late start
+        cands = [np.zeros(1, oracle.CAND_DTYPE) for _ in range(2)]
+        for b in range(2):
+            cands[b][0]["shift"] = start
+            cands[b][0]["sync"] = 0.5
+        outs = {}
+        for fused in ("1", "0"):
+            os.environ["UWSPR_SCHED_FUSED"] = fused
+            c2 = G.Context(fl=fl)
+            try:
+                outs[fused] = c2.demod_batch(fr, cands, max_per_frame=1)
+            finally:
+                c2.close()
+                os.environ.pop("UWSPR_SCHED_FUSED", None)
+        assert outs["1"].tobytes() == outs["0"].tobytes()
+        for b in range(2):
+            d = oracle.demod_candidate(cands[b][0], 1500, fr[b])
+            dfl = oracle.demod_candidate(cands[b][0], 1500, fr[b], np_points=fl)
+            o = outs["1"][b, 0]
+            assert int(o["worth_a_try"]) == d["worth_a_try"] == 1 and int(o["shift1"]) == d["shift1"]
+            for k in ("f1", "drift1", "sync1"):
+                assert np.float32(o[k]).tobytes() == np.float32(d[k]).tobytes(), (b, k)
+            assert (o["symbols"] == d["symbols"]).all() and (o["jig_sync"] == d["jig_sync"]).all()
+            assert (d["symbols"] != dfl["symbols"]).any()      # ... and np = fl would have been visible
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("threshold", [0, 1, 3, 10, 50, 10 ** 6])
@@ -725,6 +821,48 @@ def test_lazy_tries_and_resume_equal_the_eager_schedule(G, frames, vec, monkeypa
         c.close()
 
 
+def test_resume_state_is_checked_and_eager_passes_keep_no_winner_magnitudes(G, frames, vec):
+    """One context through: a lazy pass on a small batch (the winner-magnitude buffer is sized for it),
+    an EAGER pass on a larger one (must not write that buffer: it would run past its end), a lazy pass
+    again.  uwspr_demod_resume is refused after an eager pass (stale magnitudes), after a first pass
+    whose records went somewhere the resume would not patch, and for another batch shape."""
+    import torch
+    big = np.concatenate([frames, frames[::-1], frames])          # 12 frames
+    c = G.Context()
+    try:
+        _, eager_big = c.pipeline_batch(big, max_per_frame=2)
+        c.set_tries(1)
+        _, lazy_small = c.pipeline_batch(frames[:1], max_per_frame=1)
+        c.set_tries(17)
+        _, again = c.pipeline_batch(big, max_per_frame=2)          # eager, 24 slots > the 1 slot kept
+        assert again.tobytes() == eager_big.tobytes()
+        with pytest.raises(G.UwsprError):                          # the last schedule call was eager
+            c.demod_resume(big, np.ones((12, 2), np.uint8), None, max_per_frame=2)
+        c.set_tries(1)
+        _, lazy_big = c.pipeline_batch(big, max_per_frame=2)
+        with pytest.raises(G.UwsprError):                          # another batch shape
+            c.demod_resume(big[:4], np.ones((4, 2), np.uint8), None, max_per_frame=2)
+        res = c.demod_resume(big, np.ones((12, 2), np.uint8), None, max_per_frame=2)
+        assert res.tobytes() == eager_big.tobytes()
+        # first pass with host records (they live in the context): a device resume has nothing to patch
+        dev = torch.from_numpy(big).cuda()
+        od = torch.zeros(24 * G.native.DEMOD_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        c.pipeline_batch(big, max_per_frame=2)
+        with pytest.raises(G.UwsprError):
+            c.demod_resume(dev, torch.ones(24, dtype=torch.uint8, device="cuda"), od, max_per_frame=2)
+        # first pass into the caller's device buffer: a host resume would patch records it never wrote
+        cd = torch.empty(12 * c.maxfreqs * 48, dtype=torch.uint8, device="cuda")
+        nd = torch.empty(12, dtype=torch.int32, device="cuda")
+        c.pipeline_batch_into(dev, cd, nd, od, max_per_frame=2)
+        with pytest.raises(G.UwsprError):
+            c.demod_resume(big, np.ones((12, 2), np.uint8), None, max_per_frame=2)
+        c.demod_resume(dev, torch.ones(24, dtype=torch.uint8, device="cuda"), od, max_per_frame=2)
+        c.synchronize()
+        assert od.cpu().numpy().tobytes() == eager_big.tobytes()
+    finally:
+        c.close()
+
+
 def test_stream_push_frames_equal_whole_frame_calls(G, oracle):
     """uwspr_stream_*: a continuous stream pushed in ragged pieces, frames cut on the device every
     3375 samples (sliding_window_stream_to_pdu::work, cc:113-135): every sample is uploaded once,
@@ -767,6 +905,84 @@ def test_stream_push_frames_equal_whole_frame_calls(G, oracle):
                                    C.c_void_p(cands.ctypes.data), C.c_void_p(npk.ctypes.data)))
         for b in range(nfr):
             assert cands[b, :npk[b]].tobytes() == ref_c[b].tobytes()
+    finally:
+        c.close()
+
+
+def test_frames_in_place_equal_whole_frame_calls(G, oracle):
+    """Frames read where they lie (uwspr_stream_take_view + uwspr_set_frame_stride): frame j of a take
+    starts j * hop samples after the first, nothing is cut out.  A stream long enough that the ring
+    moves its tail twice (the uploads run on their own copy stream), taken in ragged groups; every
+    byte the pipeline produces from the views -- eager, lazy + resume, the flat sweep -- equals the
+    whole-frame calls on host frames sliced from the same stream; a page-locked source rewritten right
+    after uwspr_stream_push(UWSPR_HOST) returns must not disturb the stream (the call waits for its
+    DMA); the same stretch handed over as ONE strided host buffer gives the same bytes as well."""
+    import torch
+    hop, fl, nfr, maxf = 3375, 45000, 44, 3
+    base = G.synth.make_frames(5, seed=777, snr_db=-17.0)
+    stream = np.concatenate([base[k][: (10 * hop if k < 4 else fl)] for k in range(5)], axis=0)
+    stream = np.ascontiguousarray(stream[: fl + (nfr - 1) * hop])
+    assert len(stream) == fl + (nfr - 1) * hop
+    want = np.stack([stream[k * hop: k * hop + fl] for k in range(nfr)])
+    c = G.Context()
+    try:
+        ref_c, ref_o = c.pipeline_batch(want, max_per_frame=2)
+        c.stream_open(hop, maxf)
+        pinned = torch.empty((6000, 2), dtype=torch.float32).pin_memory()
+        rng = np.random.default_rng(2)
+        pos, taken = 0, 0
+        got_c, got_o = [], []
+        while taken < nfr:
+            n = min(int(rng.integers(1, 6000)), len(stream) - pos)
+            if n > 0 and (taken % 2 == 0):
+                pinned[:n] = torch.from_numpy(stream[pos: pos + n])
+                ready = c.stream_push(pinned[:n].numpy())
+                pinned[:n] = 7.0                      # the source is ours again when the call returns
+            else:
+                ready = c.stream_push(stream[pos: pos + n])
+            pos += n
+            while ready > 0 and taken < nfr:
+                k = min(ready, nfr - taken, 1 + taken % maxf)
+                ptr, stride, first = c.stream_take_view(k)
+                assert first == taken * hop and stride == hop
+                c.set_frame_stride(stride)
+                view = G.FrameView(k, ptr=ptr)
+                if taken % 4 == 1:                    # lazy first pass + resume of everything, device records
+                    c.set_tries(1)
+                    cands_t = torch.empty(k * c.maxfreqs * 48, dtype=torch.uint8, device="cuda")
+                    npk_t = torch.empty(k, dtype=torch.int32, device="cuda")
+                    out_t = torch.empty(k * 2 * G.native.DEMOD_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+                    c.pipeline_batch_into(view, cands_t, npk_t, out_t, max_per_frame=2)
+                    c.demod_resume(view, torch.ones((k, 2), dtype=torch.uint8, device="cuda"), out_t, max_per_frame=2)
+                    c.synchronize()
+                    c.set_tries(17)
+                    cn = np.frombuffer(cands_t.cpu().numpy().tobytes(), G.native.CAND_DTYPE).reshape(k, -1)
+                    nn = npk_t.cpu().numpy()
+                    cd = [cn[b, :nn[b]].copy() for b in range(k)]
+                    od = np.frombuffer(out_t.cpu().numpy().tobytes(), G.native.DEMOD_DTYPE).reshape(k, 2).copy()
+                else:
+                    cd, od = c.pipeline_batch(view, max_per_frame=2)
+                if taken % 5 == 0:                    # the flat sweep reads the same view
+                    hy = G.sweep_grid(np.array([ref_c[taken][0]]), [0])[:40]
+                    s1, y1 = c.sync_sweep(view, hy, soft=True)
+                    c.set_frame_stride(0)
+                    s2, y2 = c.sync_sweep(want[taken: taken + 1], hy, soft=True)
+                    assert s1.tobytes() == s2.tobytes() and y1.tobytes() == y2.tobytes()
+                c.set_frame_stride(0)
+                got_c += list(cd)
+                got_o.append(od)
+                taken += k
+                ready = c.stream_push(stream[0:0])
+        for a, b in zip(ref_c, got_c):
+            assert a.tobytes() == b.tobytes()
+        assert np.concatenate(got_o).tobytes() == ref_o.tobytes()
+        # one strided host buffer: the span is uploaded once
+        c.set_frame_stride(hop)
+        cd, od = c.pipeline_batch(G.FrameView(8, host=stream[: fl + 7 * hop]), max_per_frame=2)
+        c.set_frame_stride(0)
+        for a, b in zip(ref_c[:8], cd):
+            assert a.tobytes() == b.tobytes()
+        assert od.tobytes() == ref_o[:8].tobytes()
     finally:
         c.close()
 
