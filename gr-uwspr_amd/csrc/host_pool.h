@@ -1,0 +1,45 @@
+// host_pool.h -- the persistent pool of host threads behind the sequential tail of the path
+// (de-interleave + Fano per candidate: sync_and_demodulate_impl.cc:457-490 is a loop over independent
+// candidates).  Threads are created once per process and sleep between jobs; a job is a parallel-for
+// whose indices are handed out by one atomic counter, the calling thread works too.
+#pragma once
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/uwspr_hip.h"
+
+namespace uwspr {
+
+class host_pool {
+ public:
+  explicit host_pool(int nthreads);   // <= 0: one per hardware thread
+  ~host_pool();
+  int size() const { return nworkers_ + 1; }
+  // fn(i) for i in [0, n) on at most max_threads threads (<= 0: all); returns when all are done
+  void run(int n, int max_threads, const std::function<void(int)> &fn);
+  static host_pool &shared();
+
+ private:
+  void worker();
+  void drain();
+  std::vector<std::thread> threads_;
+  int nworkers_ = 0;
+  std::mutex m_, job_m_;
+  std::condition_variable cv_, cv_done_;
+  uint64_t gen_ = 0;
+  std::atomic<uint64_t> gen_a_{0};   // gen_, readable without the lock (the workers' spin)
+  bool stop_ = false;
+  const std::function<void(int)> *fn_ = nullptr;
+  std::atomic<int> next_{0};
+  int n_ = 0, chunk_ = 1, tickets_ = 0, active_ = 0;
+};
+
+// uwspr_decode_candidate from try `first` on
+int decode_candidate_from(const uwspr_demod_out *d, int first, int8_t *message7, int32_t *idt_used);
+
+}  // namespace uwspr

@@ -19,10 +19,14 @@
 #include <string.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
 #include "../../include/uwspr_hip.h"
+#include "host_pool.h"
 
 namespace {
 
@@ -65,15 +69,25 @@ struct fano_node {
 
 }  // namespace
 
-extern "C" void uwspr_deinterleave(uint8_t *sym) {
-  // destination p takes source j = bit-reversed 8-bit counter, skipping j >= 162
-  uint8_t tmp[UWSPR_NSYM];
-  int p = 0;
-  for (unsigned i = 0; p < UWSPR_NSYM; i++) {
-    unsigned j = 0;
-    for (int b = 0; b < 8; b++) j |= ((i >> b) & 1u) << (7 - b);
-    if (j < UWSPR_NSYM) tmp[p++] = sym[j];
+namespace {
+// destination p takes source j = bit-reversed 8-bit counter, skipping j >= 162 (cc:265-282)
+struct deint_table {
+  uint8_t src[UWSPR_NSYM];
+  deint_table() {
+    int p = 0;
+    for (unsigned i = 0; p < UWSPR_NSYM; i++) {
+      unsigned j = 0;
+      for (int b = 0; b < 8; b++) j |= ((i >> b) & 1u) << (7 - b);
+      if (j < UWSPR_NSYM) src[p++] = (uint8_t)j;
+    }
   }
+};
+const deint_table kDeint;
+}  // namespace
+
+extern "C" void uwspr_deinterleave(uint8_t *sym) {
+  uint8_t tmp[UWSPR_NSYM];
+  for (int p = 0; p < UWSPR_NSYM; p++) tmp[p] = sym[kDeint.src[p]];
   memcpy(sym, tmp, UWSPR_NSYM);
 }
 
@@ -96,7 +110,7 @@ extern "C" int uwspr_fano_decode(const uint8_t *symbols, uint8_t *data, uint32_t
                                  uint32_t *cycles, uint32_t *maxnp_out, int delta,
                                  uint32_t maxcycles) {
   const unsigned nbits = 81;
-  std::vector<fano_node> nodes(nbits + 1);
+  fano_node nodes[82] = {};   // per call, on the caller's stack (zeroed: a timed-out decode reports zeros for the nodes it never reached)
   const int last = (int)nbits - 1;      // index of the last node
   const int tail = (int)nbits - 31;     // first node of the all-zero tail
   unsigned maxnp = 0;
@@ -158,17 +172,17 @@ extern "C" int uwspr_fano_decode(const uint8_t *symbols, uint8_t *data, uint32_t
   return i >= budget ? -1 : 0;
 }
 
-extern "C" int uwspr_decode_candidate(const uwspr_demod_out *d, int8_t *message7, int32_t *idt_used) {
+// cc:457-490 from try `first` on (the tries before it have been attempted already: the lazy flow)
+int uwspr::decode_candidate_from(const uwspr_demod_out *d, int first, int8_t *message7, int32_t *idt_used) {
   if (!d || !message7) return 0;
   if (!d->worth_a_try) return 0;
   const float minsync2 = 0.12f;
   const float minrms = (float)(52.0 * (50 / 64.0));
-  for (int idt = 0; idt < UWSPR_NJIG; idt++) {
+  for (int idt = first < 0 ? 0 : first; idt < UWSPR_NJIG; idt++) {
     if (d->jig_sync[idt] > minsync2 && d->jig_rms[idt] > minrms) {
       uint8_t sym[UWSPR_NSYM], data[11];
       memset(data, 0, sizeof(data));
-      memcpy(sym, d->symbols[idt], UWSPR_NSYM);
-      uwspr_deinterleave(sym);
+      for (int p = 0; p < UWSPR_NSYM; p++) sym[p] = d->symbols[idt][kDeint.src[p]];
       uint32_t metric, cycles, maxnp;
       if (uwspr_fano_decode(sym, data, &metric, &cycles, &maxnp, 60, 10000) == 0) {
         for (int i = 0; i < 7; i++) message7[i] = (int8_t)data[i];
@@ -180,39 +194,105 @@ extern "C" int uwspr_decode_candidate(const uwspr_demod_out *d, int8_t *message7
   return 0;
 }
 
-// Candidates are independent (cc:389 loops over them one by one), so a batch of
-// records is decoded by a pool of host threads pulling indices from one counter;
-// record i's result does not depend on the thread count.
+extern "C" int uwspr_decode_candidate(const uwspr_demod_out *d, int8_t *message7, int32_t *idt_used) {
+  return uwspr::decode_candidate_from(d, 0, message7, idt_used);
+}
+
+// ---- the persistent host pool (host_pool.h) ------------------------------------------------------
+namespace uwspr {
+
+host_pool::host_pool(int nthreads) {
+  int n = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  nworkers_ = n - 1;   // the caller of run() is the n-th
+  for (int t = 0; t < nworkers_; t++) threads_.emplace_back([this]() { worker(); });
+}
+
+host_pool::~host_pool() {
+  {
+    std::lock_guard<std::mutex> lk(m_);
+    stop_ = true;
+  }
+  cv_.notify_all();
+  for (auto &t : threads_) t.join();
+}
+
+void host_pool::drain() {
+  for (;;) {
+    const int i0 = next_.fetch_add(chunk_, std::memory_order_relaxed);
+    if (i0 >= n_) break;
+    const int i1 = i0 + chunk_ < n_ ? i0 + chunk_ : n_;
+    for (int i = i0; i < i1; i++) (*fn_)(i);
+  }
+}
+
+void host_pool::worker() {
+  uint64_t seen = 0;
+  for (;;) {
+    // a short spin first (no lock): between the batches of a busy pipeline the next job is microseconds away
+    for (int spin = 0; spin < 1500 && gen_a_.load(std::memory_order_acquire) == seen; spin++) __builtin_ia32_pause();
+    {
+      std::unique_lock<std::mutex> lk(m_);
+      cv_.wait(lk, [&]() { return gen_ != seen || stop_; });
+      if (stop_) return;
+      seen = gen_;
+      if (tickets_ <= 0) continue;   // this job wants fewer threads
+      tickets_--;
+      active_++;
+    }
+    drain();
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      active_--;
+    }
+    cv_done_.notify_all();
+  }
+}
+
+void host_pool::run(int n, int max_threads, const std::function<void(int)> &fn) {
+  if (n <= 0) return;
+  std::lock_guard<std::mutex> job(job_m_);   // one job at a time
+  int want = max_threads > 0 ? max_threads : nworkers_ + 1;
+  if (want > n) want = n;
+  {
+    std::lock_guard<std::mutex> lk(m_);
+    fn_ = &fn; n_ = n; next_.store(0);
+    chunk_ = n / (8 * want) > 0 ? n / (8 * want) : 1;
+    if (chunk_ > 16) chunk_ = 16;
+    tickets_ = want - 1 < nworkers_ ? want - 1 : nworkers_;
+    gen_++;
+    gen_a_.store(gen_, std::memory_order_release);
+  }
+  if (want > 1) cv_.notify_all();
+  drain();
+  std::unique_lock<std::mutex> lk(m_);
+  tickets_ = 0;   // late wakers find the job finished
+  cv_done_.wait(lk, [&]() { return active_ == 0; });
+  fn_ = nullptr;
+}
+
+host_pool &host_pool::shared() {
+  static host_pool p(0);
+  return p;
+}
+
+}  // namespace uwspr
+
+// Candidates are independent (cc:389 loops over them one by one), so a batch of records is decoded
+// by the process-wide persistent pool (no thread is created or joined per call), indices handed out
+// by one counter; record i's result does not depend on the thread count.
 extern "C" int uwspr_decode_batch(const uwspr_demod_out *d, int n, int nthreads, int8_t *messages,
                                   int32_t *idt_used, uint8_t *decoded) {
   if (n < 0 || (n > 0 && (!d || !messages || !decoded))) return UWSPR_ERR_ARG;
-  if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
-  if (nthreads < 1) nthreads = 1;
-  if (nthreads > n) nthreads = n > 0 ? n : 1;
-  std::atomic<int> next(0), good(0);
-  auto work = [&]() {
-    int ok = 0;
-    for (;;) {
-      const int i = next.fetch_add(1, std::memory_order_relaxed);
-      if (i >= n) break;
-      int32_t idt = -1;
-      const int r = uwspr_decode_candidate(&d[i], messages + 7 * (size_t)i, &idt);
-      decoded[i] = (uint8_t)r;
-      if (!r) memset(messages + 7 * (size_t)i, 0, 7);
-      if (idt_used) idt_used[i] = idt;
-      ok += r;
-    }
-    good.fetch_add(ok, std::memory_order_relaxed);
-  };
-  if (nthreads == 1) {
-    work();
-  } else {
-    std::vector<std::thread> pool;
-    pool.reserve(nthreads - 1);
-    for (int t = 1; t < nthreads; t++) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
-  }
+  std::atomic<int> good(0);
+  uwspr::host_pool::shared().run(n, nthreads, [&](int i) {
+    int32_t idt = -1;
+    const int r = uwspr_decode_candidate(&d[i], messages + 7 * (size_t)i, &idt);
+    decoded[i] = (uint8_t)r;
+    if (!r) memset(messages + 7 * (size_t)i, 0, 7);
+    if (idt_used) idt_used[i] = idt;
+    if (r) good.fetch_add(1, std::memory_order_relaxed);
+  });
   return good.load();
 }
 

@@ -918,7 +918,7 @@ def test_frames_in_place_equal_whole_frame_calls(G, oracle):
     after uwspr_stream_push(UWSPR_HOST) returns must not disturb the stream (the call waits for its
     DMA); the same stretch handed over as ONE strided host buffer gives the same bytes as well."""
     import torch
-    hop, fl, nfr, maxf = 3375, 45000, 44, 3
+    hop, fl, nfr, maxf = 3375, 45000, 41, 3
     base = G.synth.make_frames(5, seed=777, snr_db=-17.0)
     stream = np.concatenate([base[k][: (10 * hop if k < 4 else fl)] for k in range(5)], axis=0)
     stream = np.ascontiguousarray(stream[: fl + (nfr - 1) * hop])
