@@ -198,6 +198,12 @@ def main():
             torch.zeros(1, device=dev)
     torch.cuda.synchronize()
 
+    # the end-to-end pipes (their contexts, lane streams and copy streams) are created here as well, for
+    # the same reason; they idle until their legs run
+    host_legs = rank == 0 and world == 1 and not args.no_host_legs and args.total_frames <= 0
+    pipe_e2e = G.Pipe(batch_frames=B, max_per_frame=1, lanes=3) if host_legs else None
+    pipe_st = G.Pipe(hop=3375, batch_frames=B, max_per_frame=1, lanes=3) if host_legs else None
+
     def make_lanes(ns, fused):
         os.environ["UWSPR_SCHED_FUSED"] = "1" if fused else "0"
         lanes = []
@@ -322,12 +328,19 @@ def main():
     # phasor recurrences (6) only where the algorithm cannot share them (the two drift tries of S2)
     ops_step = float(fine_corr) * OPS_MAC + 2.0 * nlin * OPS_PHASOR
 
-    nthr = min(16, len(os.sched_getaffinity(0)))
+    # host tail alone: de-interleave + Fano on the persistent pool (all the cores this process may use),
+    # one call per 256-record batch as the pipeline makes them
+    nthr = len(os.sched_getaffinity(0))
     G.decode_batch(out[:8, 0], nthreads=nthr)
-    t_h = time.perf_counter()
     _, _, okv = G.decode_batch(out[:, 0], nthreads=nthr)
-    host_tail = {"records": int(B), "decoded": int(okv.sum()), "threads": nthr,
-                 "records_per_s": B / (time.perf_counter() - t_h)}
+    ht = []
+    for _ in range(7):
+        t_h = time.perf_counter()
+        for _k in range(8):
+            G.decode_batch(out[:, 0], nthreads=nthr)
+        ht.append(8 * B / (time.perf_counter() - t_h))
+    host_tail = {"records": int(B), "decoded": int(okv.sum()), "threads": nthr, "calls_per_repeat": 8,
+                 "records_per_s": float(np.median(ht)), "min": min(ht), "max": max(ht)}
 
     # ---- lazy jiggered shifts: only try 0 (fused form) ----
     lazy = None
@@ -396,40 +409,84 @@ def main():
         for _ in range(3):
             ctx.pipeline_batch(pn, max_per_frame=1)
         host_pinned_rate = 3 * B / (time.perf_counter() - t2)
-    # ... and as a continuous 375 S/s STREAM (uwspr_stream_*): every step uploads only the B x 3375 new
-    # samples (from page-locked memory: one DMA), the frames are cut on the device, every result goes
-    # back to the host (page-locked buffers), one synchronisation per step.  (Running the ingest on a
-    # second HIP stream beside the search was tried: cross-stream event waits and copies in both
-    # directions made it anything from as fast to six times slower from run to run -- hardware-queue
-    # and copy-engine sharing -- so the measured form is the plain sequential one.)
-    stream_rate = None
-    if frames_cpu is not None:
+    # ---- end to end through the pipelined C-ABI driver (uwspr_pipe_*): lazy schedule || D2H of the records
+    # || Fano on the persistent host pool || resume of what try 0 did not decode; results collected on the
+    # host.  (a) decoded: the HBM-resident benchmark batches, every frame decodable -- "frames decoded/s";
+    # (b) stream: a continuous 375 S/s stream, every sample crossing PCIe once from page-locked staging
+    # buffers (uwspr_pipe_acquire / commit; the buffers are pre-filled, as a driver DMA-ing samples into
+    # them would leave them: producing the samples is not part of the path), frames every 3375 samples.
+    e2e = None
+    stream_leg = None
+    if host_legs:
+        torch.cuda.synchronize()
+        REP, KS = 5, max(50, min(K, 100))
+        pipe = pipe_e2e
+        try:
+            for i in range(6):
+                pipe.submit_device(batches[i % nb], B)
+            pipe.flush()
+            pipe.collect()
+            rates, ndec = [], 0
+            for _ in range(REP):
+                t2 = time.perf_counter()
+                got = 0
+                for i in range(KS):
+                    pipe.submit_device(batches[i % nb], B)
+                    if i % 8 == 7:
+                        got += len(pipe.collect())
+                pipe.flush()
+                r = pipe.collect()
+                got += len(r)
+                rates.append(KS * B / (time.perf_counter() - t2))
+                ndec = int(r["decoded"].sum()) if len(r) else 0
+            st = pipe.stats()
+        finally:
+            pipe.close()
+        e2e = {"frames_per_s": float(np.median(rates)), "min": min(rates), "max": max(rates), "repeats": REP,
+               "steps_per_repeat": KS, "frames_per_step": B, "lanes": 3,
+               "decoded_fraction": st["decoded"] / max(st["candidates"], 1),
+               "resumed_fraction": st["resumed"] / max(st["candidates"], 1),
+               "coordinator_s": {k: st[k] for k in ("gpu_wait_s", "fano_s", "resume_s")},
+               "what": "uwspr_pipe_submit_device: frames resident in HBM (the same rotating batches as `value`), "
+                       "FDR + lazy S0..S5 on 3 lanes, records to the host, Fano for every frame on %d host threads, "
+                       "resume + Fano for the rest, messages collected in frame order" % len(os.sched_getaffinity(0))}
+        # (b) the pushed stream
         hop = 3375
-        rng = np.random.default_rng(3)
-        chunk = torch.from_numpy((0.5 * rng.standard_normal((B * hop, 2))).astype(np.float32)).pin_memory().numpy()
-        ctx.stream_open(hop, B)
-        ctx.stream_push(frames_cpu[0][: 45000 - hop])
-        fr_t = torch.empty((B, 45000, 2), dtype=torch.float32, device=dev)
-        ln0 = lanes[0]
-        hb = (torch.empty(B, dtype=torch.int32).pin_memory(), torch.empty(ln0["cands"].numel(), dtype=torch.uint8).pin_memory(),
-              torch.empty(ln0["out"].numel(), dtype=torch.uint8).pin_memory())
-
-        def stream_step():
-            with torch.cuda.stream(ln0["stream"]):
-                ctx.stream_push(chunk)
-                ctx.stream_take(B, fr_t)
-                ln0["ctx"].pipeline_batch_into(fr_t, ln0["cands"], ln0["npk"], ln0["out"], max_per_frame=1)
-                hb[0].copy_(ln0["npk"], non_blocking=True)
-                hb[1].copy_(ln0["cands"], non_blocking=True)
-                hb[2].copy_(ln0["out"], non_blocking=True)
-            ctx.synchronize()
-
-        if ln0["ctx"] is ctx:
-            stream_step()
-            t2 = time.perf_counter()
-            for _ in range(8):
-                stream_step()
-            stream_rate = 8 * B / (time.perf_counter() - t2)
+        pipe = pipe_st
+        try:
+            rng = np.random.default_rng(3)
+            one = batches[0][:20].cpu().numpy()                     # 20 transmissions to sprinkle over the stream
+            sig = one[:, 375:375 + 162 * 256] - 0.0
+            for k in range(4):                                     # the four staging buffers, filled once
+                buf = pipe.acquire(B * hop)
+                buf[:] = (G.synth.sigma_for_snr(args.snr) * rng.standard_normal((B * hop, 2))).astype(np.float32)
+                for t in range(B * hop // 45000 - 1):
+                    s0 = t * 45000 + int(rng.integers(0, 3000))
+                    buf[s0:s0 + sig.shape[1]] += sig[t % 20]
+                pipe.commit(B * hop)
+            pipe.flush()
+            pipe.collect()
+            rates = []
+            for _ in range(REP):
+                t2 = time.perf_counter()
+                f0 = pipe.stats()["frames"]
+                for i in range(KS):
+                    pipe.acquire(B * hop)
+                    pipe.commit(B * hop)
+                    if i % 8 == 7:
+                        pipe.collect()
+                pipe.flush()
+                pipe.collect()
+                rates.append((pipe.stats()["frames"] - f0) / (time.perf_counter() - t2))
+            st = pipe.stats()
+        finally:
+            pipe.close()
+        stream_leg = {"frames_per_s": float(np.median(rates)), "min": min(rates), "max": max(rates), "repeats": REP,
+                      "steps_per_repeat": KS, "new_samples_per_step": B * hop, "bytes_uploaded_per_step": B * hop * 8,
+                      "decoded_fraction": st["decoded"] / max(st["candidates"], 1),
+                      "what": "uwspr_pipe_acquire/commit: PCIe-inclusive (every sample uploaded once on the copy "
+                              "stream, frames read in place at stride 3375, all records back to the host, Fano on "
+                              "the host pool); never `value`"}
     if args.no_cpu:
         frames_cpu = None
     result = None
@@ -494,7 +551,8 @@ def main():
             "lazy_s5": lazy,
             "host_pointer_frames_per_s_pcie_inclusive": host_rate,
             "host_pinned_pointer_frames_per_s_pcie_inclusive": host_pinned_rate,
-            "host_stream_frames_per_s_pcie_inclusive": stream_rate,
+            "end_to_end_decoded": e2e,
+            "host_stream_pcie_inclusive": stream_leg,
             "host_tail_fano": host_tail,
             "host_enqueue_ms_per_step": 1e3 * t_enq / K,
         }

@@ -470,3 +470,78 @@ def c2_read(path):
     if rc != 0:
         raise N.UwsprError(rc, "cannot read %s" % path)
     return iq, freq.value, typ.value
+
+
+class Pipe:
+    """uwspr_pipe_*: the pipelined end-to-end decoder (stream ingest on a copy stream, lazy schedule,
+    Fano on the persistent host pool under the next batch's kernels, resume of what try 0 did not
+    decode).  Results are DECODE_DTYPE records in frame order."""
+
+    def __init__(self, fs=375, fl=45000, spb=256, maxdrift=0, maxfreqs=200, halfbandwidth=10, cf=1500,
+                 threshold=10, device=0, hop=3375, batch_frames=256, max_per_frame=1, lanes=3,
+                 host_threads=0, eager=False):
+        self.L = N.lib()
+        self.h = C.c_void_p()
+        self.fl = fl
+        p = N.Params(fs, fl, spb, maxdrift, maxfreqs, halfbandwidth, cf, threshold)
+        o = N.PipeOpts(hop, batch_frames, max_per_frame, lanes, host_threads, 1 if eager else 0)
+        rc = self.L.uwspr_pipe_open(C.byref(p), device, C.byref(o), C.byref(self.h))
+        if rc != 0:
+            msg = self.L.uwspr_pipe_last_error(self.h).decode() if self.h else ""
+            if self.h:
+                self.L.uwspr_pipe_close(self.h)
+            self.h = None
+            raise N.UwsprError(rc, msg)
+        self.batch_frames, self.hop = batch_frames, hop
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise N.UwsprError(rc, self.L.uwspr_pipe_last_error(self.h).decode())
+        return rc
+
+    def close(self):
+        if self.h:
+            self.L.uwspr_pipe_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def push(self, iq):
+        a = np.ascontiguousarray(iq, np.float32)
+        self._chk(self.L.uwspr_pipe_push(self.h, C.c_void_p(a.ctypes.data), a.size // 2))
+
+    def acquire(self, nsamples):
+        """-> numpy view [nsamples, 2] of the page-locked staging buffer to fill; then commit(nsamples)."""
+        ptr = C.c_void_p()
+        self._chk(self.L.uwspr_pipe_acquire(self.h, int(nsamples), C.byref(ptr)))
+        buf = (C.c_float * (2 * int(nsamples))).from_address(ptr.value)
+        return np.frombuffer(buf, np.float32).reshape(-1, 2)
+
+    def commit(self, nsamples):
+        self._chk(self.L.uwspr_pipe_commit(self.h, int(nsamples)))
+
+    def submit_device(self, frames, B=None, stride=0):
+        """frames: torch CUDA tensor [B, fl, 2] (or a raw pointer with B given)."""
+        if _is_torch(frames):
+            B = frames.numel() // (2 * self.fl) if B is None else B
+            ptr = frames.data_ptr()
+        else:
+            ptr = int(frames)
+        self._chk(self.L.uwspr_pipe_submit_device(self.h, C.c_void_p(ptr), int(B), int(stride)))
+
+    def flush(self):
+        self._chk(self.L.uwspr_pipe_flush(self.h))
+
+    def collect(self, cap=65536, wait=False):
+        out = np.zeros(cap, N.DECODE_DTYPE)
+        n = self._chk(self.L.uwspr_pipe_collect(self.h, C.c_void_p(out.ctypes.data), cap, 1 if wait else 0))
+        return out[:n].copy()
+
+    def stats(self):
+        st = N.PipeStats()
+        self._chk(self.L.uwspr_pipe_get_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in N.PipeStats._fields_}

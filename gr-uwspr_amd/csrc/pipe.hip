@@ -1,0 +1,448 @@
+// pipe.hip -- the pipelined end-to-end decoder of include/uwspr_hip.h (uwspr_pipe_*): host code only,
+// built on the C ABI's own entry points, so what it produces is by construction what the sequential
+// calls produce -- only the ORDER IN TIME of the stages of consecutive batches differs:
+//
+//   producer thread (the caller)      copy stream          lane k's HIP stream           coordinator + pool
+//   acquire / fill / commit  ------>  H2D of new samples
+//   batch complete: view in place --------------------->   K1 K2 K3, schedule (try 0),
+//                                                          D2H of records, event  ---->  wait event
+//   (next batch: lane k+1 ...)                                                           Fano on try 0 (pool)
+//                                                          resume (tries 1..16) <------  for what did not decode
+//                                                          D2H, event            ---->   Fano on tries 1..16
+//                                                                                        results in frame order
+//
+// Reference: the flowgraph chain sliding_window_stream_to_pdu -> FDR -> sync_and_demodulate
+// (lib/sliding_window_stream_to_pdu_impl.cc:97-138, lib/FDR_impl.cc:214-456,
+// lib/sync_and_demodulate_impl.cc:315-534; the lazy tries are cc:457-490's early exit).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "host_pool.h"
+#include "uwspr_internal.h"
+
+using namespace uwspr;
+
+namespace {
+
+struct pipe_lane {
+  uwspr_ctx *ctx = nullptr;
+  hipStream_t stream = nullptr;
+  uwspr_candidate *d_cands = nullptr; int32_t *d_npk = nullptr; uwspr_demod_out *d_out = nullptr; uint8_t *d_need = nullptr;
+  uwspr_candidate *h_cands = nullptr; int32_t *h_npk = nullptr; uwspr_demod_out *h_out = nullptr; uint8_t *h_need = nullptr;
+  hipEvent_t ev_done = nullptr;
+  // the batch in flight
+  bool busy = false;
+  int B = 0, stride = 0;
+  const float *frames = nullptr;
+  int64_t frame0 = 0, pos0 = -1;
+  std::vector<uint8_t> dec;          // [B*per] decoded flags
+  std::vector<int32_t> idt;          // [B*per]
+  std::vector<int8_t> msg;           // [B*per][7]
+  std::vector<int> redo;             // records resumed
+};
+
+double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct uwspr_pipe {
+  uwspr_params p;
+  uwspr_pipe_opts o;
+  int device = 0, fl = 0, maxfreqs = 0, per = 1;
+  char err[512];
+  int failed = 0;   // sticky status of the first failure (coordinator or producer)
+
+  std::vector<pipe_lane> lanes;
+  int next_lane = 0;
+  int64_t next_frame = 0;
+
+  stream_ring ring;
+  static constexpr int NSTAGE = 4;
+  float *h_stage[NSTAGE] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t stage_ev[NSTAGE] = {nullptr, nullptr, nullptr, nullptr};
+  bool stage_busy[NSTAGE] = {false, false, false, false};
+  int stage_next = 0, stage_cur = -1;
+  size_t stage_samples = 0;
+
+  std::mutex m;
+  std::condition_variable cv_lane, cv_work, cv_done;
+  std::deque<int> inflight;
+  std::deque<uwspr_decode> done;
+  bool stop = false;
+  std::thread coord;
+  host_pool *pool = nullptr;
+  bool own_pool = false;
+  uwspr_pipe_stats st;
+};
+
+static int pfail(uwspr_pipe *q, int status, const char *fmt, ...) {
+  if (q) {
+    std::lock_guard<std::mutex> lk(q->m);
+    if (!q->failed) {
+      va_list ap;
+      va_start(ap, fmt);
+      vsnprintf(q->err, sizeof(q->err), fmt, ap);
+      va_end(ap);
+      q->failed = status;
+    }
+  }
+  return status;
+}
+
+#define PHIP(q, call)                                                                               \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess) return pfail((q), UWSPR_ERR_HIP, "%s failed: %s (%s:%d)", #call,          \
+                                       hipGetErrorString(e_), __FILE__, __LINE__);                  \
+  } while (0)
+
+// ---- coordinator: finishes the batches in launch order ------------------------------------------
+static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
+  const int per = q->per, B = L.B, nrec = B * per;
+  double t0 = now_s();
+  PHIP(q, hipEventSynchronize(L.ev_done));
+  double t1 = now_s();
+  auto valid = [&](int i) { const int b = i / per, j = i - b * per; return j < L.h_npk[b] && j < q->maxfreqs; };
+  // cc:457-490 on what the first pass produced (try 0 alone in the lazy flow)
+  q->pool->run(nrec, q->o.host_threads, [&](int i) {
+    int32_t idt = -1;
+    int r = 0;
+    if (valid(i)) r = decode_candidate_from(&L.h_out[i], 0, &L.msg[7 * (size_t)i], &idt);
+    if (!r) memset(&L.msg[7 * (size_t)i], 0, 7);
+    L.dec[i] = (uint8_t)r;
+    L.idt[i] = idt;
+  });
+  double t2 = now_s(), t3 = t2;
+  L.redo.clear();
+  if (!q->o.eager) {
+    for (int i = 0; i < nrec; i++) {
+      const bool need = valid(i) && L.h_out[i].worth_a_try && !L.dec[i];
+      L.h_need[i] = need ? 1 : 0;
+      if (need) L.redo.push_back(i);
+    }
+  }
+  if (!L.redo.empty()) {
+    // the other 16 tries of those candidates, then Fano from try 1 on
+    PHIP(q, hipMemcpyAsync(L.d_need, L.h_need, (size_t)nrec, hipMemcpyHostToDevice, L.stream));
+    int rc = uwspr_demod_resume(L.ctx, L.frames, B, UWSPR_DEVICE, L.d_need, per, L.d_out);
+    if (rc) return pfail(q, rc, "uwspr_demod_resume: %s", uwspr_last_error(L.ctx));
+    if (L.redo.size() * 4 > (size_t)nrec) {
+      PHIP(q, hipMemcpyAsync(L.h_out, L.d_out, (size_t)nrec * sizeof(uwspr_demod_out), hipMemcpyDeviceToHost, L.stream));
+    } else {
+      for (int i : L.redo)
+        PHIP(q, hipMemcpyAsync(&L.h_out[i], &L.d_out[i], sizeof(uwspr_demod_out), hipMemcpyDeviceToHost, L.stream));
+    }
+    PHIP(q, hipEventRecord(L.ev_done, L.stream));
+    PHIP(q, hipEventSynchronize(L.ev_done));
+    t3 = now_s();
+    q->pool->run((int)L.redo.size(), q->o.host_threads, [&](int k) {
+      const int i = L.redo[k];
+      int32_t idt = -1;
+      const int r = decode_candidate_from(&L.h_out[i], 1, &L.msg[7 * (size_t)i], &idt);
+      if (!r) memset(&L.msg[7 * (size_t)i], 0, 7);
+      L.dec[i] = (uint8_t)r;
+      L.idt[i] = idt;
+    });
+  }
+  double t4 = now_s();
+  int ncand = 0, ndec = 0;
+  {
+    std::lock_guard<std::mutex> lk(q->m);
+    for (int b = 0; b < B; b++) {
+      for (int j = 0; j < per; j++) {
+        const int i = b * per + j;
+        if (!valid(i)) continue;
+        uwspr_decode d;
+        memset(&d, 0, sizeof(d));
+        d.frame = L.frame0 + b;
+        d.stream_pos = L.pos0 >= 0 ? L.pos0 + (int64_t)b * L.stride : -1;
+        d.cand = j; d.npk = L.h_npk[b];
+        d.coarse = L.h_cands[(size_t)b * per + j];
+        const uwspr_demod_out &o = L.h_out[i];
+        d.f1 = o.f1; d.drift1 = o.drift1; d.sync1 = o.sync1; d.shift1 = o.shift1; d.worth_a_try = o.worth_a_try;
+        d.decoded = L.dec[i]; d.idt = L.idt[i];
+        memcpy(d.message, &L.msg[7 * (size_t)i], 7);
+        q->done.push_back(d);
+        ncand++; ndec += L.dec[i];
+      }
+    }
+    q->st.frames += B; q->st.batches += 1; q->st.candidates += ncand; q->st.decoded += ndec;
+    q->st.resumed += (int64_t)L.redo.size();
+    q->st.gpu_wait_s += (t1 - t0);
+    q->st.fano_s += (t2 - t1) + (t4 - t3);
+    q->st.resume_s += (t3 - t2);
+  }
+  return UWSPR_OK;
+}
+
+static void coordinator(uwspr_pipe *q) {
+  (void)hipSetDevice(q->device);
+  for (;;) {
+    int idx;
+    {
+      std::unique_lock<std::mutex> lk(q->m);
+      q->cv_work.wait(lk, [&]() { return q->stop || !q->inflight.empty(); });
+      if (q->inflight.empty()) return;   // stop, nothing left
+      idx = q->inflight.front();
+    }
+    pipe_lane &L = q->lanes[idx];
+    (void)finish_batch(q, L);   // a failure is sticky in q->failed; the lane is released either way
+    {
+      std::lock_guard<std::mutex> lk(q->m);
+      q->inflight.pop_front();
+      L.busy = false;
+    }
+    q->cv_lane.notify_all();
+    q->cv_done.notify_all();
+  }
+}
+
+// ---- producer side --------------------------------------------------------------------------------
+static pipe_lane *take_lane(uwspr_pipe *q) {
+  std::unique_lock<std::mutex> lk(q->m);
+  pipe_lane &L = q->lanes[q->next_lane];
+  q->cv_lane.wait(lk, [&]() { return !L.busy; });
+  L.busy = true;
+  q->next_lane = (q->next_lane + 1) % (int)q->lanes.size();
+  return &L;
+}
+
+static int launch(uwspr_pipe *q, pipe_lane &L, const float *frames, int B, int stride, int64_t pos0, int ringbuf) {
+  const int per = q->per;
+  L.B = B; L.stride = stride; L.frames = frames; L.pos0 = pos0; L.frame0 = q->next_frame;
+  q->next_frame += B;
+  int rc = uwspr_set_frame_stride(L.ctx, stride);
+  if (!rc) rc = uwspr_set_tries(L.ctx, q->o.eager ? UWSPR_NJIG : 1);
+  if (!rc) rc = uwspr_pipeline_batch(L.ctx, frames, B, UWSPR_DEVICE, per, L.d_cands, L.d_npk, L.d_out);
+  if (rc) return pfail(q, rc, "uwspr_pipeline_batch: %s", uwspr_last_error(L.ctx));
+  PHIP(q, hipMemcpyAsync(L.h_npk, L.d_npk, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, L.stream));
+  PHIP(q, hipMemcpy2DAsync(L.h_cands, (size_t)per * sizeof(uwspr_candidate), L.d_cands,
+                           (size_t)q->maxfreqs * sizeof(uwspr_candidate), (size_t)per * sizeof(uwspr_candidate), B,
+                           hipMemcpyDeviceToHost, L.stream));
+  PHIP(q, hipMemcpyAsync(L.h_out, L.d_out, (size_t)B * per * sizeof(uwspr_demod_out), hipMemcpyDeviceToHost, L.stream));
+  PHIP(q, hipEventRecord(L.ev_done, L.stream));
+  if (ringbuf >= 0) q->ring.reader_done(ringbuf, L.ev_done);
+  {
+    std::lock_guard<std::mutex> lk(q->m);
+    q->inflight.push_back((int)(&L - q->lanes.data()));
+  }
+  q->cv_work.notify_one();
+  return UWSPR_OK;
+}
+
+static void release_lane(uwspr_pipe *q, pipe_lane &L) {   // a launch that failed before it was queued
+  {
+    std::lock_guard<std::mutex> lk(q->m);
+    L.busy = false;
+  }
+  q->cv_lane.notify_all();
+}
+
+static int launch_from_ring(uwspr_pipe *q, int k) {
+  pipe_lane *L = take_lane(q);
+  const float *frames = nullptr;
+  long long pos = 0;
+  int buf = 0;
+  if (!q->ring.view(k, L->stream, &frames, &pos, &buf)) {
+    release_lane(q, *L);
+    return pfail(q, UWSPR_ERR_HIP, "stream view: %s", hipGetErrorString(q->ring.err));
+  }
+  const int rc = launch(q, *L, frames, k, q->ring.hop, pos, buf);
+  if (rc) release_lane(q, *L);
+  return rc;
+}
+
+extern "C" const char *uwspr_pipe_last_error(const uwspr_pipe *q) { return q ? q->err : "null pipe"; }
+
+extern "C" void uwspr_pipe_close(uwspr_pipe *q) {
+  if (!q) return;
+  if (q->coord.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(q->m);
+      q->stop = true;
+    }
+    q->cv_work.notify_all();
+    q->coord.join();
+  }
+  (void)hipSetDevice(q->device);
+  for (auto &L : q->lanes) {
+    if (L.stream) (void)hipStreamSynchronize(L.stream);
+    void *dev[] = {L.d_cands, L.d_npk, L.d_out, L.d_need};
+    for (void *b : dev) if (b) (void)hipFree(b);
+    void *host[] = {L.h_cands, L.h_npk, L.h_out, L.h_need};
+    for (void *b : host) if (b) (void)hipHostFree(b);
+    if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+    if (L.ctx) uwspr_ctx_destroy(L.ctx);
+  }
+  q->ring.close();
+  for (int k = 0; k < uwspr_pipe::NSTAGE; k++) {
+    if (q->h_stage[k]) (void)hipHostFree(q->h_stage[k]);
+    if (q->stage_ev[k]) (void)hipEventDestroy(q->stage_ev[k]);
+  }
+  if (q->own_pool) delete q->pool;
+  delete q;
+}
+
+extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pipe_opts *o, uwspr_pipe **out) {
+  if (!p || !o || !out) return UWSPR_ERR_ARG;
+  *out = nullptr;
+  uwspr_pipe *q = new (std::nothrow) uwspr_pipe();
+  if (!q) return UWSPR_ERR_NOMEM;
+  memset(q->err, 0, sizeof(q->err));
+  memset(&q->st, 0, sizeof(q->st));
+  q->p = *p; q->o = *o; q->device = device; q->fl = p->fl; q->maxfreqs = p->maxfreqs;
+  *out = q;   // handed back even on failure so uwspr_pipe_last_error() can be read
+  if (q->o.batch_frames <= 0) q->o.batch_frames = 256;
+  if (q->o.max_per_frame <= 0) q->o.max_per_frame = 1;
+  if (q->o.lanes <= 0) q->o.lanes = 3;
+  if (q->o.lanes > 8) q->o.lanes = 8;
+  if (q->o.hop <= 0) q->o.hop = p->fl;
+  if (q->o.hop > p->fl) return pfail(q, UWSPR_ERR_ARG, "hop=%d > fl=%d", q->o.hop, p->fl);
+  q->per = q->o.max_per_frame < p->maxfreqs ? q->o.max_per_frame : p->maxfreqs;
+  const int Bm = q->o.batch_frames, per = q->per;
+  q->lanes.resize(q->o.lanes);
+  for (auto &L : q->lanes) {
+    const int rc = uwspr_ctx_create(p, device, &L.ctx);
+    if (rc) return pfail(q, rc, "uwspr_ctx_create: %s", L.ctx ? uwspr_last_error(L.ctx) : uwspr_status_string(rc));
+    L.stream = L.ctx->own_stream;
+    PHIP(q, hipMalloc((void **)&L.d_cands, (size_t)Bm * p->maxfreqs * sizeof(uwspr_candidate)));
+    PHIP(q, hipMalloc((void **)&L.d_npk, (size_t)Bm * sizeof(int32_t)));
+    PHIP(q, hipMalloc((void **)&L.d_out, (size_t)Bm * per * sizeof(uwspr_demod_out)));
+    PHIP(q, hipMalloc((void **)&L.d_need, (size_t)Bm * per));
+    PHIP(q, hipHostMalloc((void **)&L.h_cands, (size_t)Bm * per * sizeof(uwspr_candidate), hipHostMallocDefault));
+    PHIP(q, hipHostMalloc((void **)&L.h_npk, (size_t)Bm * sizeof(int32_t), hipHostMallocDefault));
+    PHIP(q, hipHostMalloc((void **)&L.h_out, (size_t)Bm * per * sizeof(uwspr_demod_out), hipHostMallocDefault));
+    PHIP(q, hipHostMalloc((void **)&L.h_need, (size_t)Bm * per, hipHostMallocDefault));
+    // the coordinator sleeps on this event (it does not spin: the cores belong to the Fano pool)
+    PHIP(q, hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming | hipEventBlockingSync));
+    L.dec.resize((size_t)Bm * per); L.idt.resize((size_t)Bm * per); L.msg.resize((size_t)Bm * per * 7);
+  }
+  // pushed streams: the device ring (a few batches of slack beyond what can be in flight) and the
+  // page-locked staging buffers the producer fills
+  if (!q->ring.open(p->fl, q->o.hop, Bm, q->o.lanes + 3))
+    return pfail(q, UWSPR_ERR_NOMEM, "stream ring: %s", hipGetErrorString(q->ring.err));
+  q->stage_samples = (size_t)Bm * q->o.hop;
+  for (int k = 0; k < uwspr_pipe::NSTAGE; k++) {
+    PHIP(q, hipHostMalloc((void **)&q->h_stage[k], q->stage_samples * 2 * sizeof(float), hipHostMallocDefault));
+    PHIP(q, hipEventCreateWithFlags(&q->stage_ev[k], hipEventDisableTiming));
+  }
+  if (q->o.host_threads > 0) { q->pool = new host_pool(q->o.host_threads); q->own_pool = true; }
+  else q->pool = &host_pool::shared();
+  q->coord = std::thread(coordinator, q);
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_pipe_acquire(uwspr_pipe *q, int nsamples, float **iq) {
+  if (!q || !iq) return UWSPR_ERR_ARG;
+  if (q->failed) return q->failed;
+  if (nsamples <= 0 || (size_t)nsamples > q->stage_samples)
+    return pfail(q, UWSPR_ERR_ARG, "uwspr_pipe_acquire(%d): at most %zu samples per piece", nsamples, q->stage_samples);
+  (void)hipSetDevice(q->device);
+  const int s = q->stage_next;
+  if (q->stage_busy[s]) { PHIP(q, hipEventSynchronize(q->stage_ev[s])); q->stage_busy[s] = false; }
+  q->stage_cur = s;
+  *iq = q->h_stage[s];
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_pipe_commit(uwspr_pipe *q, int nsamples) {
+  if (!q) return UWSPR_ERR_ARG;
+  if (q->failed) return q->failed;
+  if (q->stage_cur < 0 || nsamples < 0 || (size_t)nsamples > q->stage_samples)
+    return pfail(q, UWSPR_ERR_ARG, "uwspr_pipe_commit(%d) without a matching uwspr_pipe_acquire", nsamples);
+  (void)hipSetDevice(q->device);
+  const int s = q->stage_cur;
+  q->stage_cur = -1;
+  if (nsamples > 0) {
+    // room behind the unconsumed samples: launch what is complete first if the ring is full
+    while (q->ring.have + (size_t)nsamples > q->ring.cap && q->ring.ready() > 0) {
+      const int rc = launch_from_ring(q, q->ring.ready() < q->o.batch_frames ? q->ring.ready() : q->o.batch_frames);
+      if (rc) return rc;
+    }
+    if (!q->ring.append(q->h_stage[s], (size_t)nsamples, false))
+      return pfail(q, UWSPR_ERR_HIP, "stream upload: %s", hipGetErrorString(q->ring.err));
+    PHIP(q, hipEventRecord(q->stage_ev[s], q->ring.copy));
+    q->stage_busy[s] = true;
+    q->stage_next = (s + 1) % uwspr_pipe::NSTAGE;
+  }
+  while (q->ring.ready() >= q->o.batch_frames) {
+    const int rc = launch_from_ring(q, q->o.batch_frames);
+    if (rc) return rc;
+  }
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_pipe_push(uwspr_pipe *q, const float *iq, int nsamples) {
+  if (!q || (nsamples > 0 && !iq) || nsamples < 0) return UWSPR_ERR_ARG;
+  size_t off = 0;
+  while (off < (size_t)nsamples) {
+    const size_t n = (size_t)nsamples - off < q->stage_samples ? (size_t)nsamples - off : q->stage_samples;
+    float *dst = nullptr;
+    int rc = uwspr_pipe_acquire(q, (int)n, &dst);
+    if (rc) return rc;
+    memcpy(dst, iq + 2 * off, n * 2 * sizeof(float));
+    if ((rc = uwspr_pipe_commit(q, (int)n))) return rc;
+    off += n;
+  }
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_pipe_submit_device(uwspr_pipe *q, const float *dev_frames, int B, int stride) {
+  if (!q || !dev_frames) return UWSPR_ERR_ARG;
+  if (q->failed) return q->failed;
+  if (B <= 0 || B > q->o.batch_frames || stride < 0)
+    return pfail(q, UWSPR_ERR_ARG, "uwspr_pipe_submit_device: B=%d (1..%d) stride=%d", B, q->o.batch_frames, stride);
+  (void)hipSetDevice(q->device);
+  pipe_lane *L = take_lane(q);
+  const int rc = launch(q, *L, dev_frames, B, stride > 0 ? stride : q->fl, -1, -1);
+  if (rc) release_lane(q, *L);
+  return rc;
+}
+
+extern "C" int uwspr_pipe_flush(uwspr_pipe *q) {
+  if (!q) return UWSPR_ERR_ARG;
+  (void)hipSetDevice(q->device);
+  while (!q->failed && q->ring.is_open() && q->ring.ready() > 0) {
+    const int k = q->ring.ready() < q->o.batch_frames ? q->ring.ready() : q->o.batch_frames;
+    const int rc = launch_from_ring(q, k);
+    if (rc) return rc;
+  }
+  std::unique_lock<std::mutex> lk(q->m);
+  q->cv_done.wait(lk, [&]() {
+    for (auto &L : q->lanes) if (L.busy) return false;
+    return true;
+  });
+  return q->failed;
+}
+
+extern "C" int uwspr_pipe_collect(uwspr_pipe *q, uwspr_decode *out, int cap, int wait) {
+  if (!q || (cap > 0 && !out) || cap < 0) return UWSPR_ERR_ARG;
+  std::unique_lock<std::mutex> lk(q->m);
+  if (wait)
+    q->cv_done.wait(lk, [&]() {
+      if (!q->done.empty() || q->failed) return true;
+      for (auto &L : q->lanes) if (L.busy) return false;
+      return true;
+    });
+  if (q->failed && q->done.empty()) return q->failed;
+  int n = 0;
+  while (n < cap && !q->done.empty()) { out[n++] = q->done.front(); q->done.pop_front(); }
+  return n;
+}
+
+extern "C" int uwspr_pipe_get_stats(uwspr_pipe *q, uwspr_pipe_stats *st) {
+  if (!q || !st) return UWSPR_ERR_ARG;
+  std::lock_guard<std::mutex> lk(q->m);
+  *st = q->st;
+  return UWSPR_OK;
+}

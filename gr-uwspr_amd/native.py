@@ -23,7 +23,7 @@ LIBPATH = os.path.join(LIBDIR, "libuwspr_hip_exp.so" if _EXTRA else "libuwspr_hi
 HOSTLIB = os.path.join(LIBDIR, "libuwspr_blocks.so")
 
 SOURCES = ["uwspr_api.hip", "k0_frontend.hip", "k1_spectrogram.hip", "k2_spectrum.hip", "k3_coarse.hip",
-           "k4_tonecorr.hip", "k5_fold_schedule.hip", "k6_sched.hip", "host_tail.cpp"]
+           "k4_tonecorr.hip", "k5_fold_schedule.hip", "k6_sched.hip", "pipe.hip", "host_tail.cpp"]
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
             "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -132,6 +132,23 @@ class Info(C.Structure):
                 ("device_name", C.c_char * 64)]
 
 
+DECODE_DTYPE = np.dtype([("frame", "<i8"), ("stream_pos", "<i8"), ("cand", "<i4"), ("npk", "<i4"),
+                         ("coarse", CAND_DTYPE), ("f1", "<f4"), ("drift1", "<f4"), ("sync1", "<f4"),
+                         ("shift1", "<i4"), ("worth_a_try", "<i4"), ("decoded", "<i4"), ("idt", "<i4"),
+                         ("message", "i1", (7,)), ("_pad", "u1", (5,))])
+assert DECODE_DTYPE.itemsize == 112
+
+
+class PipeOpts(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("hop", "batch_frames", "max_per_frame", "lanes", "host_threads", "eager")] + \
+               [("_reserved", C.c_int32 * 2)]
+
+
+class PipeStats(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("frames", "batches", "candidates", "decoded", "resumed")] + \
+               [(k, C.c_double) for k in ("gpu_wait_s", "fano_s", "resume_s")]
+
+
 K_NAMES = ("spectrogram", "spectrum", "coarse", "tonecorr", "fold", "sched")
 
 
@@ -151,6 +168,8 @@ ABI_SYMBOLS = [
     "uwspr_pipeline_batch", "uwspr_set_tries", "uwspr_demod_resume", "uwspr_pack_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
     "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_decode_batch", "uwspr_unpack_message",
     "uwspr_c2_read",
+    "uwspr_pipe_open", "uwspr_pipe_close", "uwspr_pipe_last_error", "uwspr_pipe_acquire", "uwspr_pipe_commit",
+    "uwspr_pipe_push", "uwspr_pipe_submit_device", "uwspr_pipe_flush", "uwspr_pipe_collect", "uwspr_pipe_get_stats",
 ]
 
 _lib = None
@@ -229,5 +248,17 @@ def lib():
     L.uwspr_decode_batch.restype = C.c_int
     L.uwspr_unpack_message.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.uwspr_c2_read.argtypes = [C.c_char_p, vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.uwspr_pipe_open.argtypes = [C.POINTER(Params), ip, C.POINTER(PipeOpts), C.POINTER(vp)]
+    L.uwspr_pipe_close.argtypes = [vp]
+    L.uwspr_pipe_close.restype = None
+    L.uwspr_pipe_last_error.argtypes = [vp]
+    L.uwspr_pipe_last_error.restype = C.c_char_p
+    L.uwspr_pipe_acquire.argtypes = [vp, ip, C.POINTER(vp)]
+    L.uwspr_pipe_commit.argtypes = [vp, ip]
+    L.uwspr_pipe_push.argtypes = [vp, vp, ip]
+    L.uwspr_pipe_submit_device.argtypes = [vp, vp, ip, ip]
+    L.uwspr_pipe_flush.argtypes = [vp]
+    L.uwspr_pipe_collect.argtypes = [vp, vp, ip, ip]
+    L.uwspr_pipe_get_stats.argtypes = [vp, C.POINTER(PipeStats)]
     _lib = L
     return L

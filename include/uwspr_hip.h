@@ -312,6 +312,64 @@ int uwspr_pipeline_batch(uwspr_ctx *ctx, const float *frames, int B, int where,
  * = 32 + 48*K bytes per frame; slabs: [B][32+48K]. */
 int uwspr_pack_slabs(uwspr_ctx *ctx, int B, int K, void *slabs, int where);
 
+/* ---- pipelined end-to-end decoder ---------------------------------------------------------- */
+/* The whole receive chain of examples/WaveFilePlusNoiseDecode.grc behind one object:
+ *   sliding_window_stream_to_pdu (lib/sliding_window_stream_to_pdu_impl.cc:97-138)  -> frames in place
+ *   FDR::transform               (lib/FDR_impl.cc:214-456)                          -> candidates
+ *   sync_and_demodulate::demodulate (lib/sync_and_demodulate_impl.cc:315-534)       -> 7-byte messages
+ * with the stages of CONSECUTIVE batches overlapped: page-locked samples go up on a copy stream while
+ * the batches before are searched; the schedule produces only the first jiggered shift
+ * (uwspr_set_tries(1): the reference stops at its first decoding try, cc:457-490); Fano runs on a
+ * persistent pool of host threads under the kernels of the next batch; the candidates whose first
+ * try did not decode are resumed on the GPU (uwspr_demod_resume) and tried again.  Results are
+ * byte-for-byte those of the sequential calls (uwspr_pipeline_batch with all 17 tries +
+ * uwspr_decode_batch), in frame order.  One producer thread drives a pipe. */
+typedef struct uwspr_pipe uwspr_pipe;
+typedef struct uwspr_pipe_opts {
+  int32_t hop;            /* samples between frame starts (shift*fs = 3375); pushed streams only */
+  int32_t batch_frames;   /* frames per GPU batch (256) */
+  int32_t max_per_frame;  /* candidates refined per frame (cc:389 refines all npk; 1 = the strongest) */
+  int32_t lanes;          /* batches in flight, each with its own context and HIP stream (0: 3) */
+  int32_t host_threads;   /* Fano threads (0: one per hardware thread) */
+  int32_t eager;          /* 1: all 17 tries in the first pass, no resume (A/B against the lazy flow) */
+  int32_t _reserved[2];
+} uwspr_pipe_opts;
+/* one refined candidate (j < min(npk, max_per_frame)) of one frame */
+typedef struct uwspr_decode {
+  int64_t frame;          /* running index of the frame in submission order */
+  int64_t stream_pos;     /* index of its first sample in the pushed stream (-1: submitted frames) */
+  int32_t cand, npk;      /* rank of this candidate, candidates found in the frame */
+  uwspr_candidate coarse; /* the FDR record (candidate_t) */
+  float f1, drift1, sync1;
+  int32_t shift1, worth_a_try;
+  int32_t decoded;        /* 1: message holds the 7 bytes sync_and_demodulate publishes (cc:528-530) */
+  int32_t idt;            /* the jiggered try that decoded (-1: none) */
+  int8_t message[7];
+  uint8_t _pad[5];
+} uwspr_decode;
+typedef struct uwspr_pipe_stats {
+  int64_t frames, batches, candidates, decoded, resumed;   /* resumed: records whose other tries were produced */
+  double gpu_wait_s, fano_s, resume_s;                     /* coordinator thread: where its time went */
+} uwspr_pipe_stats;
+int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pipe_opts *o, uwspr_pipe **out);
+void uwspr_pipe_close(uwspr_pipe *pipe);
+const char *uwspr_pipe_last_error(const uwspr_pipe *pipe);
+/* A page-locked buffer for the next nsamples (I,Q) pairs of the stream (at most batch_frames*hop): fill it,
+ * then commit.  Blocks only while every staging buffer still has its upload in flight. */
+int uwspr_pipe_acquire(uwspr_pipe *pipe, int nsamples, float **iq);
+int uwspr_pipe_commit(uwspr_pipe *pipe, int nsamples);
+/* acquire + memcpy + commit for samples that live elsewhere */
+int uwspr_pipe_push(uwspr_pipe *pipe, const float *iq, int nsamples);
+/* B frames already in device memory (frame b at frames + 2*stride*b floats, stride 0 = fl): searched as one
+ * batch.  The memory must stay valid until the batch's results have been collected. */
+int uwspr_pipe_submit_device(uwspr_pipe *pipe, const float *dev_frames, int B, int stride);
+/* launch what is complete (a last, short batch of a pushed stream) and wait for everything in flight */
+int uwspr_pipe_flush(uwspr_pipe *pipe);
+/* up to cap finished records in frame order; wait != 0: block until at least one is there or nothing is
+ * in flight.  returns the count (>= 0) or a negative status. */
+int uwspr_pipe_collect(uwspr_pipe *pipe, uwspr_decode *out, int cap, int wait);
+int uwspr_pipe_get_stats(uwspr_pipe *pipe, uwspr_pipe_stats *st);
+
 /* ---- measurement -------------------------------------------------------- */
 enum { UWSPR_K_SPECTROGRAM = 0, UWSPR_K_SPECTRUM = 1, UWSPR_K_COARSE = 2,
        UWSPR_K_TONECORR = 3, UWSPR_K_FOLD = 4, UWSPR_K_SCHED = 5, UWSPR_K_COUNT = 6 };
