@@ -73,7 +73,8 @@ def cpu_baseline(frames_np, budget_s=12.0):
     import oracle_py as O
     O.lib()
     O.pr3()
-    ncores = max(1, min(16, len(os.sched_getaffinity(0))))
+    import gr_uwspr_amd as _G
+    ncores = max(1, min(16, _G.host_threads()))
     fdrs = [O.FDR() for _ in range(ncores)]
 
     def one(args):
@@ -330,7 +331,7 @@ def main():
 
     # host tail alone: de-interleave + Fano on the persistent pool (all the cores this process may use),
     # one call per 256-record batch as the pipeline makes them
-    nthr = len(os.sched_getaffinity(0))
+    nthr = G.host_threads()                  # affinity and cgroup CPU quota applied
     G.decode_batch(out[:8, 0], nthreads=nthr)
     _, _, okv = G.decode_batch(out[:, 0], nthreads=nthr)
     ht = []
@@ -426,7 +427,7 @@ def main():
                 pipe.submit_device(batches[i % nb], B)
             pipe.flush()
             pipe.collect()
-            rates, ndec = [], 0
+            prates, ndec = [], 0
             for _ in range(REP):
                 t2 = time.perf_counter()
                 got = 0
@@ -437,19 +438,19 @@ def main():
                 pipe.flush()
                 r = pipe.collect()
                 got += len(r)
-                rates.append(KS * B / (time.perf_counter() - t2))
+                prates.append(KS * B / (time.perf_counter() - t2))
                 ndec = int(r["decoded"].sum()) if len(r) else 0
             st = pipe.stats()
         finally:
             pipe.close()
-        e2e = {"frames_per_s": float(np.median(rates)), "min": min(rates), "max": max(rates), "repeats": REP,
+        e2e = {"frames_per_s": float(np.median(prates)), "min": min(prates), "max": max(prates), "repeats": REP,
                "steps_per_repeat": KS, "frames_per_step": B, "lanes": 3,
                "decoded_fraction": st["decoded"] / max(st["candidates"], 1),
                "resumed_fraction": st["resumed"] / max(st["candidates"], 1),
                "coordinator_s": {k: st[k] for k in ("gpu_wait_s", "fano_s", "resume_s")},
                "what": "uwspr_pipe_submit_device: frames resident in HBM (the same rotating batches as `value`), "
                        "FDR + lazy S0..S5 on 3 lanes, records to the host, Fano for every frame on %d host threads, "
-                       "resume + Fano for the rest, messages collected in frame order" % len(os.sched_getaffinity(0))}
+                       "resume + Fano for the rest, messages collected in frame order" % max(1, G.host_threads() - 2)}
         # (b) the pushed stream
         hop = 3375
         pipe = pipe_st
@@ -466,7 +467,7 @@ def main():
                 pipe.commit(B * hop)
             pipe.flush()
             pipe.collect()
-            rates = []
+            prates = []
             for _ in range(REP):
                 t2 = time.perf_counter()
                 f0 = pipe.stats()["frames"]
@@ -477,11 +478,11 @@ def main():
                         pipe.collect()
                 pipe.flush()
                 pipe.collect()
-                rates.append((pipe.stats()["frames"] - f0) / (time.perf_counter() - t2))
+                prates.append((pipe.stats()["frames"] - f0) / (time.perf_counter() - t2))
             st = pipe.stats()
         finally:
             pipe.close()
-        stream_leg = {"frames_per_s": float(np.median(rates)), "min": min(rates), "max": max(rates), "repeats": REP,
+        stream_leg = {"frames_per_s": float(np.median(prates)), "min": min(prates), "max": max(prates), "repeats": REP,
                       "steps_per_repeat": KS, "new_samples_per_step": B * hop, "bytes_uploaded_per_step": B * hop * 8,
                       "decoded_fraction": st["decoded"] / max(st["candidates"], 1),
                       "what": "uwspr_pipe_acquire/commit: PCIe-inclusive (every sample uploaded once on the copy "

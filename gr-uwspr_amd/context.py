@@ -432,6 +432,11 @@ def decode_candidate(demod_rec):
     return (msg, idt.value) if ok else None
 
 
+def host_threads():
+    """CPUs this process may keep busy (affinity and cgroup quota applied)."""
+    return int(N.lib().uwspr_host_threads())
+
+
 def decode_batch(demod_recs, nthreads=0):
     """demod_recs: DEMOD_DTYPE array (any shape). -> (messages [n,7] int8, idt [n] int32,
     decoded [n] bool), record order kept; Fano runs on `nthreads` host threads."""

@@ -15,9 +15,11 @@
 
 namespace uwspr {
 
+int host_cpu_share();   // hardware threads capped by affinity and by the cgroup CPU quota
+
 class host_pool {
  public:
-  explicit host_pool(int nthreads);   // <= 0: one per hardware thread
+  explicit host_pool(int nthreads);   // <= 0: host_cpu_share()
   ~host_pool();
   int size() const { return nworkers_ + 1; }
   // fn(i) for i in [0, n) on at most max_threads threads (<= 0: all); returns when all are done

@@ -14,6 +14,7 @@
 //   message unpack      lib/helpers.cc:321-590 (without the on-disk hash table)
 //   .c2 layout          lib/c2file_source_impl.cc:80-96
 #include <math.h>
+#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -201,8 +202,35 @@ extern "C" int uwspr_decode_candidate(const uwspr_demod_out *d, int8_t *message7
 // ---- the persistent host pool (host_pool.h) ------------------------------------------------------
 namespace uwspr {
 
+// The CPUs this process may actually keep busy: hardware threads, capped by the scheduler affinity
+// mask and by the cgroup CPU quota (a container that sees 256 hardware threads may own 16 of them;
+// more runnable threads than that only get the whole group throttled).
+int host_cpu_share() {
+  int n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+    const int a = CPU_COUNT(&set);
+    if (a > 0 && a < n) n = a;
+  }
+  long long quota = -1, period = -1;
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {            // cgroup v2: "<quota|max> <period>"
+    char q[64];
+    if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+    fclose(f);
+  } else {
+    if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+    if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = -1; fclose(g); }
+  }
+  if (quota > 0 && period > 0) {
+    const int c = (int)((quota + period - 1) / period);
+    if (c >= 1 && c < n) n = c;
+  }
+  return n;
+}
+
 host_pool::host_pool(int nthreads) {
-  int n = nthreads > 0 ? nthreads : (int)std::thread::hardware_concurrency();
+  int n = nthreads > 0 ? nthreads : host_cpu_share();
   if (n < 1) n = 1;
   nworkers_ = n - 1;   // the caller of run() is the n-th
   for (int t = 0; t < nworkers_; t++) threads_.emplace_back([this]() { worker(); });
@@ -230,7 +258,7 @@ void host_pool::worker() {
   uint64_t seen = 0;
   for (;;) {
     // a short spin first (no lock): between the batches of a busy pipeline the next job is microseconds away
-    for (int spin = 0; spin < 1500 && gen_a_.load(std::memory_order_acquire) == seen; spin++) __builtin_ia32_pause();
+    for (int spin = 0; spin < 200 && gen_a_.load(std::memory_order_acquire) == seen; spin++) __builtin_ia32_pause();
     {
       std::unique_lock<std::mutex> lk(m_);
       cv_.wait(lk, [&]() { return gen_ != seen || stop_; });
@@ -281,6 +309,8 @@ host_pool &host_pool::shared() {
 // Candidates are independent (cc:389 loops over them one by one), so a batch of records is decoded
 // by the process-wide persistent pool (no thread is created or joined per call), indices handed out
 // by one counter; record i's result does not depend on the thread count.
+extern "C" int uwspr_host_threads(void) { return uwspr::host_cpu_share(); }
+
 extern "C" int uwspr_decode_batch(const uwspr_demod_out *d, int n, int nthreads, int8_t *messages,
                                   int32_t *idt_used, uint8_t *decoded) {
   if (n < 0 || (n > 0 && (!d || !messages || !decoded))) return UWSPR_ERR_ARG;

@@ -336,8 +336,8 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
     PHIP(q, hipHostMalloc((void **)&q->h_stage[k], q->stage_samples * 2 * sizeof(float), hipHostMallocDefault));
     PHIP(q, hipEventCreateWithFlags(&q->stage_ev[k], hipEventDisableTiming));
   }
-  if (q->o.host_threads > 0) { q->pool = new host_pool(q->o.host_threads); q->own_pool = true; }
-  else q->pool = &host_pool::shared();
+  if (q->o.host_threads <= 0) q->o.host_threads = host_cpu_share() > 3 ? host_cpu_share() - 2 : 1;
+  q->pool = &host_pool::shared();   // the process-wide pool; this pipe's jobs use host_threads of it
   q->coord = std::thread(coordinator, q);
   return UWSPR_OK;
 }

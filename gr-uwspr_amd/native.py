@@ -166,7 +166,7 @@ ABI_SYMBOLS = [
     "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
     "uwspr_sync_sweep", "uwspr_sync_grid", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
     "uwspr_pipeline_batch", "uwspr_set_tries", "uwspr_demod_resume", "uwspr_pack_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
-    "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_decode_batch", "uwspr_unpack_message",
+    "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_host_threads", "uwspr_decode_batch", "uwspr_unpack_message",
     "uwspr_c2_read",
     "uwspr_pipe_open", "uwspr_pipe_close", "uwspr_pipe_last_error", "uwspr_pipe_acquire", "uwspr_pipe_commit",
     "uwspr_pipe_push", "uwspr_pipe_submit_device", "uwspr_pipe_flush", "uwspr_pipe_collect", "uwspr_pipe_get_stats",
@@ -246,6 +246,7 @@ def lib():
     L.uwspr_decode_candidate.argtypes = [vp, vp, C.POINTER(C.c_int32)]
     L.uwspr_decode_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.uwspr_decode_batch.restype = C.c_int
+    L.uwspr_host_threads.argtypes = []
     L.uwspr_unpack_message.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.uwspr_c2_read.argtypes = [C.c_char_p, vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.uwspr_pipe_open.argtypes = [C.POINTER(Params), ip, C.POINTER(PipeOpts), C.POINTER(vp)]

@@ -330,7 +330,7 @@ typedef struct uwspr_pipe_opts {
   int32_t batch_frames;   /* frames per GPU batch (256) */
   int32_t max_per_frame;  /* candidates refined per frame (cc:389 refines all npk; 1 = the strongest) */
   int32_t lanes;          /* batches in flight, each with its own context and HIP stream (0: 3) */
-  int32_t host_threads;   /* Fano threads (0: one per hardware thread) */
+  int32_t host_threads;   /* Fano threads (0: uwspr_host_threads() - 2, leaving the producer and the HIP runtime a core each) */
   int32_t eager;          /* 1: all 17 tries in the first pass, no resume (A/B against the lazy flow) */
   int32_t _reserved[2];
 } uwspr_pipe_opts;
@@ -407,6 +407,9 @@ int uwspr_fano_encode(uint8_t *symbols, const uint8_t *data, uint32_t nbytes);
  * Fano in reference order.  returns 1 and fills message7 on decode, else 0. */
 int uwspr_decode_candidate(const uwspr_demod_out *d, int8_t *message7,
                            int32_t *idt_used);
+/* CPUs this process may keep busy: hardware threads capped by the affinity mask and the cgroup CPU
+ * quota (what "one per hardware thread" means below). */
+int uwspr_host_threads(void);
 /* The same for n records on `nthreads` host threads (<= 0: one per hardware
  * thread): the per-candidate loop of cc:389 with its Fano calls spread over the
  * host cores.  messages [n][7] (zero when not decoded), idt_used [n] or NULL,

@@ -85,7 +85,7 @@ def test_pipe_on_device_frames_equals_the_sequential_calls(G, eager):
 def test_pipe_on_a_pushed_stream_equals_the_sequential_calls(G):
     """A 375 S/s stream pushed in ragged pieces (pageable memory through uwspr_pipe_push, page-locked
     through acquire / commit): frames every 3375 samples, batches of 8, a short last batch on flush."""
-    hop, fl, nfr, per = 3375, 45000, 29, 1
+    hop, fl, nfr, per = 3375, 45000, 27, 1
     base = G.synth.make_frames(4, seed=31415, snr_db=-18.0)
     stream = np.concatenate([base[k][: 10 * hop] for k in range(4)], axis=0)
     stream = np.ascontiguousarray(stream[: fl + (nfr - 1) * hop])
@@ -118,7 +118,7 @@ def test_pipe_on_a_pushed_stream_equals_the_sequential_calls(G):
     assert st["frames"] == nfr and st["batches"] == 4
     assert (recs["stream_pos"] == recs["frame"] * hop).all()
     assert _as_dict(recs) == exp
-    assert sum(v[3] for v in exp.values()) >= 4                # the transmissions decode in their own windows
+    assert sum(v[3] for v in exp.values()) >= 3                # the transmissions decode in their own windows
 
 
 @pytest.mark.gpu
