@@ -202,8 +202,8 @@ def main():
     # the end-to-end pipes (their contexts, lane streams and copy streams) are created here as well, for
     # the same reason; they idle until their legs run
     host_legs = rank == 0 and world == 1 and not args.no_host_legs and args.total_frames <= 0
-    pipe_e2e = G.Pipe(batch_frames=B, max_per_frame=1, lanes=3) if host_legs else None
-    pipe_st = G.Pipe(hop=3375, batch_frames=B, max_per_frame=1, lanes=3) if host_legs else None
+    pipes_e2e = {f: G.Pipe(batch_frames=B, max_per_frame=1, lanes=3, sched=f) for f in ("fused", "staged")} if host_legs else {}
+    pipe_st = G.Pipe(hop=3375, batch_frames=B, max_per_frame=1, lanes=3, sched="staged") if host_legs else None
 
     def make_lanes(ns, fused):
         os.environ["UWSPR_SCHED_FUSED"] = "1" if fused else "0"
@@ -421,73 +421,86 @@ def main():
     if host_legs:
         torch.cuda.synchronize()
         REP, KS = 5, max(50, min(K, 100))
-        pipe = pipe_e2e
-        try:
-            for i in range(6):
-                pipe.submit_device(batches[i % nb], B)
-            pipe.flush()
-            pipe.collect()
-            prates, ndec = [], 0
-            for _ in range(REP):
-                t2 = time.perf_counter()
-                got = 0
-                for i in range(KS):
+        by_form = {}
+        for form, pipe in pipes_e2e.items():
+            try:
+                for i in range(3 * nb):
                     pipe.submit_device(batches[i % nb], B)
-                    if i % 8 == 7:
-                        got += len(pipe.collect())
                 pipe.flush()
-                r = pipe.collect()
-                got += len(r)
-                prates.append(KS * B / (time.perf_counter() - t2))
-                ndec = int(r["decoded"].sum()) if len(r) else 0
-            st = pipe.stats()
-        finally:
-            pipe.close()
-        e2e = {"frames_per_s": float(np.median(prates)), "min": min(prates), "max": max(prates), "repeats": REP,
-               "steps_per_repeat": KS, "frames_per_step": B, "lanes": 3,
-               "decoded_fraction": st["decoded"] / max(st["candidates"], 1),
-               "resumed_fraction": st["resumed"] / max(st["candidates"], 1),
-               "coordinator_s": {k: st[k] for k in ("gpu_wait_s", "fano_s", "resume_s")},
-               "what": "uwspr_pipe_submit_device: frames resident in HBM (the same rotating batches as `value`), "
-                       "FDR + lazy S0..S5 on 3 lanes, records to the host, Fano for every frame on %d host threads, "
-                       "resume + Fano for the rest, messages collected in frame order" % max(1, G.host_threads() - 2)}
-        # (b) the pushed stream
+                pipe.collect()
+                prates = []
+                for _ in range(REP):
+                    t2 = time.perf_counter()
+                    for i in range(KS):
+                        pipe.submit_device(batches[i % nb], B)
+                        if i % 8 == 7:
+                            pipe.collect()
+                    pipe.flush()
+                    pipe.collect()
+                    prates.append(KS * B / (time.perf_counter() - t2))
+                st = pipe.stats()
+            finally:
+                pipe.close()
+            by_form[form] = {"frames_per_s": float(np.median(prates)), "min": min(prates), "max": max(prates),
+                             "decoded_fraction": st["decoded"] / max(st["candidates"], 1),
+                             "resumed_fraction": st["resumed"] / max(st["candidates"], 1),
+                             "fano_calls_per_frame": st["fano_calls"] / max(st["frames"], 1),
+                             "fano_timeouts_per_frame": st["fano_timeouts"] / max(st["frames"], 1),
+                             "coordinator_s": {k: st[k] for k in ("gpu_wait_s", "fano_s", "resume_s")}}
+        best = max(by_form, key=lambda f: by_form[f]["frames_per_s"])
+        e2e = dict(by_form[best])
+        e2e.update({"sched": best, "by_sched": {f: v["frames_per_s"] for f, v in by_form.items()}, "repeats": REP,
+                    "steps_per_repeat": KS, "frames_per_step": B, "lanes": 3, "host_threads": max(1, G.host_threads() - 2),
+                    "what": "uwspr_pipe_submit_device: frames resident in HBM (the same rotating batches as `value`), "
+                            "FDR + lazy S0..S5 on 3 lanes, records to the host, Fano for every frame on the persistent "
+                            "host pool, resume + Fano for what try 0 did not decode, messages collected in frame order"})
+        # (b) the pushed stream, twice: a QUIET stream (noise, a transmission only every 40th frame length:
+        # a window without one never reaches Fano -- the ingest rate) and a BUSY one (a transmission in every
+        # window: 12 of 13 windows see it outside the search range, a few of their tries pass the gates
+        # (cc:470) and run Fano to its 10000-cycles-per-bit time-out on the host -- the reference's cost)
         hop = 3375
         pipe = pipe_st
+        stream_leg = {}
         try:
             rng = np.random.default_rng(3)
             one = batches[0][:20].cpu().numpy()                     # 20 transmissions to sprinkle over the stream
             sig = one[:, 375:375 + 162 * 256] - 0.0
-            for k in range(4):                                     # the four staging buffers, filled once
-                buf = pipe.acquire(B * hop)
-                buf[:] = (G.synth.sigma_for_snr(args.snr) * rng.standard_normal((B * hop, 2))).astype(np.float32)
-                for t in range(B * hop // 45000 - 1):
-                    s0 = t * 45000 + int(rng.integers(0, 3000))
-                    buf[s0:s0 + sig.shape[1]] += sig[t % 20]
-                pipe.commit(B * hop)
-            pipe.flush()
-            pipe.collect()
-            prates = []
-            for _ in range(REP):
-                t2 = time.perf_counter()
-                f0 = pipe.stats()["frames"]
-                for i in range(KS):
-                    pipe.acquire(B * hop)
+            for name, every in (("quiet", 40), ("busy", 1)):
+                for k in range(4):                                 # the four staging buffers, filled once
+                    buf = pipe.acquire(B * hop)
+                    buf[:] = (G.synth.sigma_for_snr(args.snr) * rng.standard_normal((B * hop, 2))).astype(np.float32)
+                    for t in range(0, B * hop // 45000 - 1, every):
+                        s0 = t * 45000 + int(rng.integers(0, 3000))
+                        buf[s0:s0 + sig.shape[1]] += sig[t % 20]
                     pipe.commit(B * hop)
-                    if i % 8 == 7:
-                        pipe.collect()
                 pipe.flush()
                 pipe.collect()
-                prates.append((pipe.stats()["frames"] - f0) / (time.perf_counter() - t2))
-            st = pipe.stats()
+                st0 = pipe.stats()
+                prates = []
+                ks = KS if name == "quiet" else 8
+                for _ in range(REP if name == "quiet" else 2):
+                    t2 = time.perf_counter()
+                    f0 = pipe.stats()["frames"]
+                    for i in range(ks):
+                        pipe.acquire(B * hop)
+                        pipe.commit(B * hop)
+                        if i % 8 == 7:
+                            pipe.collect()
+                    pipe.flush()
+                    pipe.collect()
+                    prates.append((pipe.stats()["frames"] - f0) / (time.perf_counter() - t2))
+                st = pipe.stats()
+                nf = max(st["frames"] - st0["frames"], 1)
+                stream_leg[name] = {"frames_per_s": float(np.median(prates)), "min": min(prates), "max": max(prates),
+                                    "repeats": len(prates), "steps_per_repeat": ks,
+                                    "decoded_per_frame": (st["decoded"] - st0["decoded"]) / nf,
+                                    "fano_timeouts_per_frame": (st["fano_timeouts"] - st0["fano_timeouts"]) / nf}
         finally:
             pipe.close()
-        stream_leg = {"frames_per_s": float(np.median(prates)), "min": min(prates), "max": max(prates), "repeats": REP,
-                      "steps_per_repeat": KS, "new_samples_per_step": B * hop, "bytes_uploaded_per_step": B * hop * 8,
-                      "decoded_fraction": st["decoded"] / max(st["candidates"], 1),
-                      "what": "uwspr_pipe_acquire/commit: PCIe-inclusive (every sample uploaded once on the copy "
-                              "stream, frames read in place at stride 3375, all records back to the host, Fano on "
-                              "the host pool); never `value`"}
+        stream_leg.update({"new_samples_per_step": B * hop, "bytes_uploaded_per_step": B * hop * 8,
+                           "what": "uwspr_pipe_acquire/commit: PCIe-inclusive (every sample uploaded once on the copy "
+                                   "stream from page-locked staging buffers, frames read in place at stride 3375, all "
+                                   "records back to the host, gates + Fano on the host pool); never `value`"})
     if args.no_cpu:
         frames_cpu = None
     result = None

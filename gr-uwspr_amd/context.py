@@ -484,12 +484,13 @@ class Pipe:
 
     def __init__(self, fs=375, fl=45000, spb=256, maxdrift=0, maxfreqs=200, halfbandwidth=10, cf=1500,
                  threshold=10, device=0, hop=3375, batch_frames=256, max_per_frame=1, lanes=3,
-                 host_threads=0, eager=False):
+                 host_threads=0, eager=False, sched=None):
         self.L = N.lib()
         self.h = C.c_void_p()
         self.fl = fl
         p = N.Params(fs, fl, spb, maxdrift, maxfreqs, halfbandwidth, cf, threshold)
-        o = N.PipeOpts(hop, batch_frames, max_per_frame, lanes, host_threads, 1 if eager else 0)
+        o = N.PipeOpts(hop, batch_frames, max_per_frame, lanes, host_threads, 1 if eager else 0,
+                       {None: 0, "fused": 1, "staged": 2}[sched], 0)
         rc = self.L.uwspr_pipe_open(C.byref(p), device, C.byref(o), C.byref(self.h))
         if rc != 0:
             msg = self.L.uwspr_pipe_last_error(self.h).decode() if self.h else ""

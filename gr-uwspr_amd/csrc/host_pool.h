@@ -42,6 +42,7 @@ class host_pool {
 };
 
 // uwspr_decode_candidate from try `first` on
-int decode_candidate_from(const uwspr_demod_out *d, int first, int8_t *message7, int32_t *idt_used);
+int decode_candidate_from(const uwspr_demod_out *d, int first, int8_t *message7, int32_t *idt_used,
+                          int *fano_calls = nullptr);
 
 }  // namespace uwspr

@@ -174,7 +174,8 @@ extern "C" int uwspr_fano_decode(const uint8_t *symbols, uint8_t *data, uint32_t
 }
 
 // cc:457-490 from try `first` on (the tries before it have been attempted already: the lazy flow)
-int uwspr::decode_candidate_from(const uwspr_demod_out *d, int first, int8_t *message7, int32_t *idt_used) {
+int uwspr::decode_candidate_from(const uwspr_demod_out *d, int first, int8_t *message7, int32_t *idt_used,
+                                 int *fano_calls) {
   if (!d || !message7) return 0;
   if (!d->worth_a_try) return 0;
   const float minsync2 = 0.12f;
@@ -185,6 +186,7 @@ int uwspr::decode_candidate_from(const uwspr_demod_out *d, int first, int8_t *me
       memset(data, 0, sizeof(data));
       for (int p = 0; p < UWSPR_NSYM; p++) sym[p] = d->symbols[idt][kDeint.src[p]];
       uint32_t metric, cycles, maxnp;
+      if (fano_calls) (*fano_calls)++;
       if (uwspr_fano_decode(sym, data, &metric, &cycles, &maxnp, 60, 10000) == 0) {
         for (int i = 0; i < 7; i++) message7[i] = (int8_t)data[i];
         if (idt_used) *idt_used = idt;

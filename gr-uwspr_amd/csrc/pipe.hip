@@ -18,6 +18,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -114,10 +115,12 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
   double t1 = now_s();
   auto valid = [&](int i) { const int b = i / per, j = i - b * per; return j < L.h_npk[b] && j < q->maxfreqs; };
   // cc:457-490 on what the first pass produced (try 0 alone in the lazy flow)
+  std::atomic<long long> calls(0);
   q->pool->run(nrec, q->o.host_threads, [&](int i) {
     int32_t idt = -1;
-    int r = 0;
-    if (valid(i)) r = decode_candidate_from(&L.h_out[i], 0, &L.msg[7 * (size_t)i], &idt);
+    int r = 0, nc = 0;
+    if (valid(i)) r = decode_candidate_from(&L.h_out[i], 0, &L.msg[7 * (size_t)i], &idt, &nc);
+    if (nc) calls.fetch_add(nc, std::memory_order_relaxed);
     if (!r) memset(&L.msg[7 * (size_t)i], 0, 7);
     L.dec[i] = (uint8_t)r;
     L.idt[i] = idt;
@@ -148,7 +151,9 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
     q->pool->run((int)L.redo.size(), q->o.host_threads, [&](int k) {
       const int i = L.redo[k];
       int32_t idt = -1;
-      const int r = decode_candidate_from(&L.h_out[i], 1, &L.msg[7 * (size_t)i], &idt);
+      int nc = 0;
+      const int r = decode_candidate_from(&L.h_out[i], 1, &L.msg[7 * (size_t)i], &idt, &nc);
+      if (nc) calls.fetch_add(nc, std::memory_order_relaxed);
       if (!r) memset(&L.msg[7 * (size_t)i], 0, 7);
       L.dec[i] = (uint8_t)r;
       L.idt[i] = idt;
@@ -178,6 +183,7 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
     }
     q->st.frames += B; q->st.batches += 1; q->st.candidates += ncand; q->st.decoded += ndec;
     q->st.resumed += (int64_t)L.redo.size();
+    q->st.fano_calls += calls.load(); q->st.fano_timeouts += calls.load() - ndec;
     q->st.gpu_wait_s += (t1 - t0);
     q->st.fano_s += (t2 - t1) + (t4 - t3);
     q->st.resume_s += (t3 - t2);
@@ -315,6 +321,8 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
     const int rc = uwspr_ctx_create(p, device, &L.ctx);
     if (rc) return pfail(q, rc, "uwspr_ctx_create: %s", L.ctx ? uwspr_last_error(L.ctx) : uwspr_status_string(rc));
     L.stream = L.ctx->own_stream;
+    if (q->o.sched_form == 1) L.ctx->use_fused = true;
+    if (q->o.sched_form == 2) L.ctx->use_fused = false;
     PHIP(q, hipMalloc((void **)&L.d_cands, (size_t)Bm * p->maxfreqs * sizeof(uwspr_candidate)));
     PHIP(q, hipMalloc((void **)&L.d_npk, (size_t)Bm * sizeof(int32_t)));
     PHIP(q, hipMalloc((void **)&L.d_out, (size_t)Bm * per * sizeof(uwspr_demod_out)));

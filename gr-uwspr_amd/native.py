@@ -140,12 +140,13 @@ assert DECODE_DTYPE.itemsize == 112
 
 
 class PipeOpts(C.Structure):
-    _fields_ = [(k, C.c_int32) for k in ("hop", "batch_frames", "max_per_frame", "lanes", "host_threads", "eager")] + \
-               [("_reserved", C.c_int32 * 2)]
+    _fields_ = [(k, C.c_int32) for k in ("hop", "batch_frames", "max_per_frame", "lanes", "host_threads", "eager",
+                                         "sched_form", "_reserved")]
 
 
 class PipeStats(C.Structure):
-    _fields_ = [(k, C.c_int64) for k in ("frames", "batches", "candidates", "decoded", "resumed")] + \
+    _fields_ = [(k, C.c_int64) for k in ("frames", "batches", "candidates", "decoded", "resumed", "fano_calls",
+                                         "fano_timeouts")] + \
                [(k, C.c_double) for k in ("gpu_wait_s", "fano_s", "resume_s")]
 
 

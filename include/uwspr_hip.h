@@ -332,7 +332,8 @@ typedef struct uwspr_pipe_opts {
   int32_t lanes;          /* batches in flight, each with its own context and HIP stream (0: 3) */
   int32_t host_threads;   /* Fano threads (0: uwspr_host_threads() - 2, leaving the producer and the HIP runtime a core each) */
   int32_t eager;          /* 1: all 17 tries in the first pass, no resume (A/B against the lazy flow) */
-  int32_t _reserved[2];
+  int32_t sched_form;     /* 0: as the contexts default (UWSPR_SCHED_FUSED), 1: fused kernel, 2: staged launches */
+  int32_t _reserved;
 } uwspr_pipe_opts;
 /* one refined candidate (j < min(npk, max_per_frame)) of one frame */
 typedef struct uwspr_decode {
@@ -349,6 +350,7 @@ typedef struct uwspr_decode {
 } uwspr_decode;
 typedef struct uwspr_pipe_stats {
   int64_t frames, batches, candidates, decoded, resumed;   /* resumed: records whose other tries were produced */
+  int64_t fano_calls, fano_timeouts;                       /* tries that passed the gates (cc:470) / ran to the cycle limit */
   double gpu_wait_s, fano_s, resume_s;                     /* coordinator thread: where its time went */
 } uwspr_pipe_stats;
 int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pipe_opts *o, uwspr_pipe **out);
