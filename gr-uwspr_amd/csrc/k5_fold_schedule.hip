@@ -189,6 +189,96 @@ __device__ __forceinline__ float fold_wave(const dev_hyp *__restrict__ hyps,
   return sync;
 }
 
+// The same fold with NO LDS at all: every lane keeps its three symbols' terms in registers and the
+// order-sensitive running sums walk them with v_readlane (the symbol index is wave-uniform, so the
+// lane select is a constant); all 64 lanes carry the same sums.  About twice the instructions of the
+// LDS form per fold (a readlane per term) -- but the schedule's fold kernels run beside the tone
+// correlation launches of the other batches, which hold most of every CU's LDS: the 26 KB workgroups
+// of the LDS form waited for LDS for 40-65 us where the fold itself takes 6 (round-2 overlap profile);
+// a workgroup that needs registers only is placed at once.
+__device__ __forceinline__ float rl_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+__device__ __forceinline__ double rl_d(double v, int l) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <bool SOFT>
+__device__ __forceinline__ float fold_wave_rl(const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p,
+                                              int h, float symfac, uint8_t *__restrict__ symbols) {
+  const int lane = threadIdx.x & 63;
+  if (hyps[h].frame < 0) {
+    if (SOFT)
+      for (int i = lane; i < UWSPR_NSYM; i += 64) symbols[(size_t)h * UWSPR_NSYM + i] = 0;
+    return -1e30f;
+  }
+  float4 P[3];
+  float cm[3], fs[3];
+  double q0[3], q1[3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int i = lane + 64 * r;
+    P[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); cm[r] = 0.0f; fs[r] = 0.0f; q0[r] = 0.0; q1[r] = 0.0;
+    if (i < UWSPR_NSYM) {
+      P[r] = p[(size_t)h * UWSPR_NSYM + i];
+      const bool bit = pr3_rt(i);
+      const float cmet = (P[r].y + P[r].w) - (P[r].x + P[r].z);   // cc:214
+      cm[r] = bit ? cmet : -cmet;                                  // ss -/+ cmet == ss + (-/+cmet)
+      fs[r] = bit ? P[r].w - P[r].y : P[r].z - P[r].x;             // cc:219,222
+      if (SOFT) {
+        q0[r] = (double)fs[r] / 162.0;                             // cc:243
+        q1[r] = (double)(fs[r] * fs[r]) / 162.0;                   // cc:244
+      }
+    }
+  }
+  float totp = 0.0f, ss = 0.0f, fsum = 0.0f, f2sum = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+#pragma unroll
+    for (int l = 0; l < 64; l++) {
+      if (64 * r + l >= UWSPR_NSYM) continue;
+      // cc:213: totp = (((totp+p0)+p1)+p2)+p3; cc:215: ss
+      totp = totp + rl_f(P[r].x, l); totp = totp + rl_f(P[r].y, l);
+      totp = totp + rl_f(P[r].z, l); totp = totp + rl_f(P[r].w, l);
+      ss = ss + rl_f(cm[r], l);
+      if (SOFT) {
+        fsum = (float)((double)fsum + rl_d(q0[r], l));
+        f2sum = (float)((double)f2sum + rl_d(q1[r], l));
+      }
+    }
+  }
+  const float sync = ieee_divf(ss, totp);  // cc:226
+  if (SOFT) {
+    const float fac = ieee_sqrtf(f2sum - fsum * fsum);  // cc:246
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const int i = lane + 64 * r;
+      if (i < UWSPR_NSYM) {
+        float v = ieee_divf(symfac * fs[r], fac);  // cc:248
+        if (v > 127.0f) v = 127.0f;
+        if (v < -128.0f) v = -128.0f;
+        v = v + 128.0f;
+        symbols[(size_t)h * UWSPR_NSYM + i] = (v != v) ? (uint8_t)0 : (uint8_t)(int)v;
+      }
+    }
+  }
+  return sync;
+}
+
+template <bool SOFT>
+__global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave_rl(
+    const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p, int H, float symfac,
+    float *__restrict__ sync, uint8_t *__restrict__ symbols) {
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = blockIdx.x * K5W_WAVES + wv;
+  if (h >= H) return;  // wave-uniform
+  const float s = fold_wave_rl<SOFT>(hyps, p, h, symfac, symbols);
+  if ((threadIdx.x & 63) == 0) sync[h] = s;
+}
+
 template <bool SOFT>
 __global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave(
     const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p, int H, float symfac,
@@ -211,8 +301,13 @@ void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, floa
   const bool lanes_form = forced >= 0 ? forced != 0 : H >= 32768;
   if (!lanes_form) {
     dim3 g((H + K5W_WAVES - 1) / K5W_WAVES), b(64 * K5W_WAVES);
-    if (symbols) hipLaunchKernelGGL(k5_fold_wave<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
-    else hipLaunchKernelGGL(k5_fold_wave<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
+    if (c->use_k5_lds) {
+      if (symbols) hipLaunchKernelGGL(k5_fold_wave<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
+      else hipLaunchKernelGGL(k5_fold_wave<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
+    } else {
+      if (symbols) hipLaunchKernelGGL(k5_fold_wave_rl<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
+      else hipLaunchKernelGGL(k5_fold_wave_rl<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
+    }
   } else {
     hipLaunchKernelGGL(k5_fold, dim3((H + 63) / 64), dim3(64), 0, c->stream, hyps, p, H, 50.0f,
                        sync, symbols);
@@ -436,21 +531,23 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
 
 // Fold of a candidate's NIN hypotheses (one wavefront each) fused with the
 // schedule transition that consumes them: one workgroup per candidate slot.
-template <int STAGE>
+template <int STAGE, bool LDS>
 __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__restrict__ hin,
                              const float4 *__restrict__ p, float *__restrict__ sync,
                              dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
                              uwspr_candidate *__restrict__ cent, int32_t *__restrict__ cframe, int nslots,
                              int reuse, int njig) {
   constexpr int NIN = STAGE == 3 ? 2 : 5;
-  __shared__ k5_wave_lds L[NIN];
+  __shared__ k5_wave_lds L[LDS ? NIN : 1];
   __shared__ float sy[NIN];
   const int slot = blockIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = slot * NIN + wv;
   // a hypothesis marked known (frame <= -2) repeats the previous winner: its metric is in the state
-  const float s = (hin[h].frame <= -2) ? state[slot].csync
-                                       : fold_wave<false>(hin, p, h, 50.0f, nullptr, L[wv], nullptr);
+  float s;
+  if (hin[h].frame <= -2) s = state[slot].csync;
+  else if (LDS) s = fold_wave<false>(hin, p, h, 50.0f, nullptr, L[LDS ? wv : 0], nullptr);
+  else s = fold_wave_rl<false>(hin, p, h, 50.0f, nullptr);
   if ((threadIdx.x & 63) == 0) { sy[wv] = s; sync[h] = s; }
   __syncthreads();
   if (STAGE == 5) {
@@ -544,12 +641,27 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots, int njig) {
   dev_hyp *hin = (stage & 1) ? half0 : half1;
   dev_hyp *hout = (stage & 1) ? half1 : half0;
   dim3 g(nslots);
-  switch (stage) {
-    case 1: hipLaunchKernelGGL(k5_fold_step<1>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0, njig); break;
-    case 2: hipLaunchKernelGGL(k5_fold_step<2>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0, njig); break;
-    case 3: hipLaunchKernelGGL(k5_fold_step<3>, g, dim3(128), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0, njig); break;
-    case 4: hipLaunchKernelGGL(k5_fold_step<4>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0, njig); break;
-    default: hipLaunchKernelGGL(k5_fold_step<5>, g, dim3(320), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps, c->d_cent, c->d_cent_frame, nslots, c->reuse_centre ? 1 : 0, njig); break;
+  const int reuse = c->reuse_centre ? 1 : 0;
+  auto go = [&](auto kern, int threads) {
+    hipLaunchKernelGGL(kern, g, dim3(threads), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps,
+                       c->d_cent, c->d_cent_frame, nslots, reuse, njig);
+  };
+  if (c->use_k5_lds) {
+    switch (stage) {
+      case 1: go(k5_fold_step<1, true>, 320); break;
+      case 2: go(k5_fold_step<2, true>, 320); break;
+      case 3: go(k5_fold_step<3, true>, 128); break;
+      case 4: go(k5_fold_step<4, true>, 320); break;
+      default: go(k5_fold_step<5, true>, 320); break;
+    }
+  } else {
+    switch (stage) {
+      case 1: go(k5_fold_step<1, false>, 320); break;
+      case 2: go(k5_fold_step<2, false>, 320); break;
+      case 3: go(k5_fold_step<3, false>, 128); break;
+      case 4: go(k5_fold_step<4, false>, 320); break;
+      default: go(k5_fold_step<5, false>, 320); break;
+    }
   }
 }
 

@@ -302,11 +302,12 @@ def test_schedule_without_lag_groups_is_identical(G, frames, vec, monkeypatch):
     cands = [vec["cands"][b, :int(vec["npk"][b])] for b in range(4)]
     per = max(len(c) for c in cands)
     outs = []
-    for groups, stage_grid, ring, fstage, reuse, fused in (
-            ("1", "1", "1", "0", "1", "0"), ("0", "0", "1", "0", "0", "0"), ("1", "0", "0", "1", "1", "0"),
-            ("0", "1", "0", "0", "0", "0"), ("1", "0", "1", "1", "1", "0"), ("0", "0", "0", "1", "0", "0"),
-            ("1", "0", "1", "1", "0", "0"), ("0", "0", "0", "0", "1", "0"),
-            ("1", "0", "1", "1", "1", "1"), ("1", "0", "1", "1", "0", "1")):
+    for groups, stage_grid, ring, fstage, reuse, fused, k5lds in (
+            ("1", "1", "1", "0", "1", "0", "0"), ("0", "0", "1", "0", "0", "0", "1"), ("1", "0", "0", "1", "1", "0", "0"),
+            ("0", "1", "0", "0", "0", "0", "1"), ("1", "0", "1", "1", "1", "0", "0"), ("0", "0", "0", "1", "0", "0", "0"),
+            ("1", "0", "1", "1", "0", "0", "1"), ("0", "0", "0", "0", "1", "0", "0"), ("1", "0", "1", "1", "1", "0", "1"),
+            ("1", "0", "1", "1", "1", "1", "0"), ("1", "0", "1", "1", "0", "1", "0")):
+        monkeypatch.setenv("UWSPR_K5_LDS", k5lds)            # wave folds: LDS form vs register / v_readlane form
         monkeypatch.setenv("UWSPR_SCHED_FUSED", fused)       # one workgroup per candidate (k6_sched) vs staged launches
         monkeypatch.setenv("UWSPR_K4_GROUPS", groups)        # lag sweeps: k4_group vs k4_tonecorr
         monkeypatch.setenv("UWSPR_K4_STAGE_GRID", stage_grid)  # freq/drift stages: k4_grid vs k4_tonecorr
