@@ -531,24 +531,28 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
 
 // Fold of a candidate's NIN hypotheses (one wavefront each) fused with the
 // schedule transition that consumes them: one workgroup per candidate slot.
-template <int STAGE, bool LDS>
+// LDS: the folds go through LDS (fold_wave) or registers (fold_wave_rl).  ONEWAVE: one wavefront folds the
+// slot's hypotheses one after the other (5 KB of LDS per workgroup instead of 26 KB).
+template <int STAGE, bool LDS, bool ONEWAVE>
 __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__restrict__ hin,
                              const float4 *__restrict__ p, float *__restrict__ sync,
                              dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
                              uwspr_candidate *__restrict__ cent, int32_t *__restrict__ cframe, int nslots,
                              int reuse, int njig) {
   constexpr int NIN = STAGE == 3 ? 2 : 5;
-  __shared__ k5_wave_lds L[LDS ? NIN : 1];
+  __shared__ k5_wave_lds L[LDS ? (ONEWAVE ? 1 : NIN) : 1];
   __shared__ float sy[NIN];
   const int slot = blockIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = slot * NIN + wv;
-  // a hypothesis marked known (frame <= -2) repeats the previous winner: its metric is in the state
-  float s;
-  if (hin[h].frame <= -2) s = state[slot].csync;
-  else if (LDS) s = fold_wave<false>(hin, p, h, 50.0f, nullptr, L[LDS ? wv : 0], nullptr);
-  else s = fold_wave_rl<false>(hin, p, h, 50.0f, nullptr);
-  if ((threadIdx.x & 63) == 0) { sy[wv] = s; sync[h] = s; }
+  for (int q = ONEWAVE ? 0 : wv; q < (ONEWAVE ? NIN : wv + 1); q++) {
+    const int h = slot * NIN + q;
+    // a hypothesis marked known (frame <= -2) repeats the previous winner: its metric is in the state
+    float s;
+    if (hin[h].frame <= -2) s = state[slot].csync;
+    else if (LDS) s = fold_wave<false>(hin, p, h, 50.0f, nullptr, L[(LDS && !ONEWAVE) ? q : 0], nullptr);
+    else s = fold_wave_rl<false>(hin, p, h, 50.0f, nullptr);
+    if ((threadIdx.x & 63) == 0) { sy[q] = s; sync[h] = s; }
+  }
   __syncthreads();
   if (STAGE == 5) {
     if (threadIdx.x < UWSPR_NJIG + 3)
@@ -646,21 +650,30 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots, int njig) {
     hipLaunchKernelGGL(kern, g, dim3(threads), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps,
                        c->d_cent, c->d_cent_frame, nslots, reuse, njig);
   };
-  if (c->use_k5_lds) {
+  const bool one = c->k5_onewave;
+  if (c->use_k5_lds && !one) {
     switch (stage) {
-      case 1: go(k5_fold_step<1, true>, 320); break;
-      case 2: go(k5_fold_step<2, true>, 320); break;
-      case 3: go(k5_fold_step<3, true>, 128); break;
-      case 4: go(k5_fold_step<4, true>, 320); break;
-      default: go(k5_fold_step<5, true>, 320); break;
+      case 1: go(k5_fold_step<1, true, false>, 320); break;
+      case 2: go(k5_fold_step<2, true, false>, 320); break;
+      case 3: go(k5_fold_step<3, true, false>, 128); break;
+      case 4: go(k5_fold_step<4, true, false>, 320); break;
+      default: go(k5_fold_step<5, true, false>, 320); break;
+    }
+  } else if (c->use_k5_lds) {
+    switch (stage) {
+      case 1: go(k5_fold_step<1, true, true>, 64); break;
+      case 2: go(k5_fold_step<2, true, true>, 64); break;
+      case 3: go(k5_fold_step<3, true, true>, 64); break;
+      case 4: go(k5_fold_step<4, true, true>, 64); break;
+      default: go(k5_fold_step<5, true, true>, 64); break;
     }
   } else {
     switch (stage) {
-      case 1: go(k5_fold_step<1, false>, 320); break;
-      case 2: go(k5_fold_step<2, false>, 320); break;
-      case 3: go(k5_fold_step<3, false>, 128); break;
-      case 4: go(k5_fold_step<4, false>, 320); break;
-      default: go(k5_fold_step<5, false>, 320); break;
+      case 1: go(k5_fold_step<1, false, false>, 320); break;
+      case 2: go(k5_fold_step<2, false, false>, 320); break;
+      case 3: go(k5_fold_step<3, false, false>, 128); break;
+      case 4: go(k5_fold_step<4, false, false>, 320); break;
+      default: go(k5_fold_step<5, false, false>, 320); break;
     }
   }
 }

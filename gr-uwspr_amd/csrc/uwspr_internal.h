@@ -145,7 +145,8 @@ struct uwspr_ctx {
   bool use_fstage;       // S1/S4 through the frequency-stage form (UWSPR_K4_FSTAGE=0: flat kernel)
   bool reuse_centre;     // skip the stage-winner hypothesis in S1/S3/S4 (UWSPR_K4_REUSE=0: recompute it)
   bool use_lag_ring;     // S3/S5 groups through the LDS-ring form (UWSPR_K4_RING=0: plain groups)
-  bool use_k5_lds;       // wave folds through LDS (UWSPR_K5_LDS=1) instead of the register / v_readlane form
+  bool use_k5_lds;       // wave folds through LDS (default); UWSPR_K5_LDS=0: the register / v_readlane form
+  bool k5_onewave;       // UWSPR_K5_ONEWAVE=1: one wavefront per slot folds its hypotheses in turn (5 KB LDS, not 26)
   // fused schedule (k6_sched: one workgroup per candidate runs S0..S5; UWSPR_SCHED_FUSED=0: staged launches)
   bool use_fused; bool sched_nopad; int sched_grid;
   size_t cap_tabs; float *d_tabs;     // [sched_grid][2][5][4][256](c, s) phasor tables
