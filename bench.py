@@ -117,6 +117,9 @@ def parse_args():
     ap.add_argument("--sched", choices=("auto", "fused", "staged"), default="auto",
                     help="schedule form: k6_sched (one workgroup per candidate), the staged K4/K5 launches, "
                          "or whichever measures faster in a short trial (recorded in config.sched)")
+    ap.add_argument("--gather", choices=("auto", "abi", "torch"), default="auto",
+                    help="final slab gather: the library's own RCCL gather (uwspr_dist_*), torch.distributed, or "
+                         "auto = the former when its communicator comes up (checked once against the latter)")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams (each with its own context and scratch) the steps rotate over; 0 = per --sched trial")
     return ap.parse_args()
@@ -125,8 +128,8 @@ def parse_args():
 def spawn_ranks(args):
     """`--gpus N` run bare: one child process per rank, started before the parent touches the
     GPU.  Rank 0's stdout (the JSON line) is passed through."""
-    import torch
-    ndev = torch.cuda.device_count()          # does not initialise the GPU
+    # (the parent makes no GPU-runtime call at all: every rank counts the devices it sees itself and
+    # falls back to the gloo rehearsal when there are fewer devices than ranks)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -136,8 +139,6 @@ def spawn_ranks(args):
         env = os.environ.copy()
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        if ndev < args.gpus:                   # rehearsal: ranks share the devices, gloo between them
-            env["UWSPR_BENCH_BACKEND"] = "gloo"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
@@ -238,6 +239,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the gather: the library's RCCL gather (C ABI) when its communicator comes up, else torch's ----
+    gather_how = "none (one rank)" if world == 1 else "torch.distributed (%s)" % backend
+    abi_ctx = None
+    gather_recv = None
+    if world > 1 and backend == "nccl" and args.gather in ("auto", "abi"):
+        import threading
+        gctx = G.Context(device=local)
+        state = {"ok": False, "err": None}
+
+        def _init():
+            try:
+                uid_t = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    uid_t.copy_(torch.frombuffer(bytearray(G.Context.dist_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid_t, src=0)
+                gctx.dist_init(rank, world, bytes(uid_t.cpu().numpy().tobytes()))
+                state["ok"] = True
+            except Exception as e:                       # noqa: BLE001 -- any failure means: use torch's gather
+                state["err"] = repr(e)
+
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(120.0)                                   # a communicator that does not come up in 2 min is given up
+        okt = torch.tensor([1 if (state["ok"] and not th.is_alive()) else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 1:
+            abi_ctx = gctx
+            gather_how = "uwspr_dist_gather (RCCL send/recv to the root, C ABI)"
+        else:
+            gather_how += "; C-ABI RCCL communicator not used: %s" % (state["err"] or "timed out")
+
+    def gather_to_root(flat):
+        """flat: [n, SLAB_BYTES] uint8 on the device -> [world, n, SLAB_BYTES] on rank 0 (None elsewhere)."""
+        nonlocal gather_recv
+        if abi_ctx is None:
+            return D.gather_slabs(flat, dst=0)
+        if rank == 0 and (gather_recv is None or gather_recv.numel() != world * flat.numel()):
+            gather_recv = torch.empty((world,) + tuple(flat.shape), dtype=torch.uint8, device=dev)
+        abi_ctx.dist_gather(flat, gather_recv if rank == 0 else None, root=0)
+        abi_ctx.synchronize()
+        return gather_recv if rank == 0 else None
+
     def region(lanes, steps, gather=True):
         """K steps between barrier + synchronize (+ the one gather); seconds, max over ranks."""
         barrier()
@@ -246,7 +289,7 @@ def main():
             step(lanes, i)
         t_enq = time.perf_counter() - t0
         torch.cuda.synchronize()
-        g = D.gather_slabs(slab_ring.view(K * Bmax, D.SLAB_BYTES), dst=0) if gather else None
+        g = gather_to_root(slab_ring.view(K * Bmax, D.SLAB_BYTES)) if gather else None
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -286,6 +329,11 @@ def main():
     for _ in range(max(1, args.repeats)):
         dt, t_enq, gathered = region(lanes, K)
         reps.append((dt, t_enq))
+    gather_checked = None
+    if abi_ctx is not None:          # once, outside the timed regions: the two gathers give the same bytes
+        ref = D.gather_slabs(slab_ring.view(K * Bmax, D.SLAB_BYTES), dst=0)
+        if rank == 0:
+            gather_checked = bool(torch.equal(ref.to(dev), gathered))
     order = sorted(range(len(reps)), key=lambda r: reps[r][0])
     dt, t_enq = reps[order[len(order) // 2]]
     frames_per_step = args.total_frames if strong else world * B
@@ -543,7 +591,8 @@ def main():
                        "streams_per_gpu": ns,
                        "trial_ms_per_step": {("%s x%d streams" % ("fused" if f else "staged", s)): 1e3 * v / K
                                              for (f, s), v in trials.items()},
-                       "rehearsal_ranks_share_devices": bool(rehearsal), "backend": backend, "devices": min(ndev, world)},
+                       "rehearsal_ranks_share_devices": bool(rehearsal), "backend": backend, "devices": min(ndev, world),
+                       "gather": gather_how, "gather_equals_torch_gather": gather_checked},
             "roofline": {"kernel": "k6_sched" if fused else "k4_* (6 launches)", "bound": "valu_fp32_nofma",
                          "achieved": achieved_tops, "peak": FP32_NOFMA_PEAK_TOPS, "unit": "Top/s",
                          "frac": achieved_tops / FP32_NOFMA_PEAK_TOPS,

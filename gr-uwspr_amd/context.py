@@ -368,6 +368,29 @@ class Context:
                                           C.c_void_p(sync_t.data_ptr()),
                                           C.c_void_p(sym_t.data_ptr()) if sym_t is not None else None))
 
+    # -- multi-GPU gather over RCCL (uwspr_dist_*) ---------------------------
+    @staticmethod
+    def dist_unique_id():
+        """rank 0: the 128 bytes every rank passes to dist_init (ncclGetUniqueId)."""
+        buf = (C.c_char * 128)()
+        rc = N.lib().uwspr_dist_unique_id(buf)
+        if rc != 0:
+            raise N.UwsprError(rc, "uwspr_dist_unique_id: RCCL unavailable")
+        return bytes(buf)
+
+    def dist_init(self, rank, world, uid=None):
+        self._chk(self.L.uwspr_dist_init(self.h, int(rank), int(world), uid))
+
+    def dist_gather(self, send_t, recv_t=None, root=0):
+        """send_t: torch CUDA tensor (this rank's slabs); recv_t: [world * send bytes] on the root."""
+        nbytes = send_t.numel() * send_t.element_size()
+        self._chk(self.L.uwspr_dist_gather(self.h, C.c_void_p(send_t.data_ptr()), nbytes,
+                                           C.c_void_p(recv_t.data_ptr()) if recv_t is not None else None,
+                                           int(root), N.DEVICE))
+
+    def dist_finalize(self):
+        self._chk(self.L.uwspr_dist_finalize(self.h))
+
     # -- measurement -------------------------------------------------------
     def prof_enable(self, which=True):
         """which: True = every kernel family, False/0 = off, or an iterable of

@@ -119,6 +119,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   // flat kernel at 5 hypotheses per candidate (4 waves/SIMD, window loads not overlapped): opt-in
   c->use_stage_grid = getenv("UWSPR_K4_STAGE_GRID") && atoi(getenv("UWSPR_K4_STAGE_GRID")) != 0;
   c->cap_slab = 0; c->d_slab = nullptr;
+  c->dist_comm = nullptr; c->dist_rank = 0; c->dist_world = 0;
   c->sched_grid = getenv("UWSPR_SCHED_GRID") ? atoi(getenv("UWSPR_SCHED_GRID")) : 0;
   c->cap_tmpc = 0; c->d_tmpc = nullptr; c->cap_tmpn = 0; c->d_tmpn = nullptr;
   c->h_pin = nullptr; c->pin_busy[0] = c->pin_busy[1] = false;
@@ -274,6 +275,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
 
 extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   if (!c) return;
+  (void)uwspr_dist_finalize(c);
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
   void *bufs[] = {c->d_window, c->d_twiddle, c->d_k3_tile, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
                   c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_cent,

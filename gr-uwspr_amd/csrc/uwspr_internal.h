@@ -168,6 +168,8 @@ struct uwspr_ctx {
   bool last_sched_lazy; uwspr_demod_out *last_sched_out;   // what uwspr_demod_resume may continue (run_schedule)
   unsigned long long *d_sched_stamps; size_t cap_sched_stamps;   // UWSPR_SCHED_STAMPS=1: phase times of the last launch
   size_t cap_slab; uint8_t *d_slab;
+  // multi-GPU gather (dist.hip): RCCL communicator of this rank, or null (single rank / not initialised)
+  void *dist_comm; int dist_rank, dist_world;
 
   int prof_mask;
   std::vector<uwspr::ev_pair> prof_events;

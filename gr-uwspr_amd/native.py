@@ -23,7 +23,7 @@ LIBPATH = os.path.join(LIBDIR, "libuwspr_hip_exp.so" if _EXTRA else "libuwspr_hi
 HOSTLIB = os.path.join(LIBDIR, "libuwspr_blocks.so")
 
 SOURCES = ["uwspr_api.hip", "k0_frontend.hip", "k1_spectrogram.hip", "k2_spectrum.hip", "k3_coarse.hip",
-           "k4_tonecorr.hip", "k5_fold_schedule.hip", "k6_sched.hip", "pipe.hip", "host_tail.cpp"]
+           "k4_tonecorr.hip", "k5_fold_schedule.hip", "k6_sched.hip", "pipe.hip", "dist.hip", "host_tail.cpp"]
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
             "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -72,7 +72,7 @@ def build(force=False, verbose=False):
     deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     deps.append(os.path.join(_HERE, "..", "include", "uwspr_hip.h"))
     extra = _EXTRA   # experiments only (separate output file, see LIBPATH)
-    cmd = [_hipcc()] + HIPFLAGS + extra + ["-shared", "-pthread"] + srcs + ["-o", LIBPATH]
+    cmd = [_hipcc()] + HIPFLAGS + extra + ["-shared", "-pthread"] + srcs + ["-ldl", "-o", LIBPATH]
     stamp = LIBPATH + ".cmd"
     want = " ".join(cmd) + "\n" + _digest(deps)
     same = os.path.exists(LIBPATH) and os.path.exists(stamp) and open(stamp).read() == want
@@ -169,6 +169,7 @@ ABI_SYMBOLS = [
     "uwspr_pipeline_batch", "uwspr_set_tries", "uwspr_demod_resume", "uwspr_pack_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
     "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_host_threads", "uwspr_decode_batch", "uwspr_unpack_message",
     "uwspr_c2_read",
+    "uwspr_dist_unique_id", "uwspr_dist_init", "uwspr_dist_gather", "uwspr_dist_finalize",
     "uwspr_pipe_open", "uwspr_pipe_close", "uwspr_pipe_last_error", "uwspr_pipe_acquire", "uwspr_pipe_commit",
     "uwspr_pipe_push", "uwspr_pipe_submit_device", "uwspr_pipe_flush", "uwspr_pipe_collect", "uwspr_pipe_get_stats",
 ]
@@ -250,6 +251,10 @@ def lib():
     L.uwspr_host_threads.argtypes = []
     L.uwspr_unpack_message.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.uwspr_c2_read.argtypes = [C.c_char_p, vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.uwspr_dist_unique_id.argtypes = [vp]
+    L.uwspr_dist_init.argtypes = [vp, ip, ip, vp]
+    L.uwspr_dist_gather.argtypes = [vp, vp, C.c_size_t, vp, ip, ip]
+    L.uwspr_dist_finalize.argtypes = [vp]
     L.uwspr_pipe_open.argtypes = [C.POINTER(Params), ip, C.POINTER(PipeOpts), C.POINTER(vp)]
     L.uwspr_pipe_close.argtypes = [vp]
     L.uwspr_pipe_close.restype = None

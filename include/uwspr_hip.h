@@ -312,6 +312,23 @@ int uwspr_pipeline_batch(uwspr_ctx *ctx, const float *frames, int B, int where,
  * = 32 + 48*K bytes per frame; slabs: [B][32+48K]. */
 int uwspr_pack_slabs(uwspr_ctx *ctx, int B, int K, void *slabs, int where);
 
+/* ---- multi-GPU: the final gather over RCCL --------------------------------------- */
+/* One process per GPU, frames sharded round-robin (global frame b on rank b mod G), no data-path
+ * collective; the one exchange is the gather of the uwspr_pack_slabs output to the root rank:
+ * point-to-point RCCL transfers (ncclSend / ncclRecv in one group), each peer -> root over its own xGMI
+ * link.  librccl is loaded on first use; world == 1 needs no RCCL at all (the gather is a copy).
+ *   uwspr_dist_unique_id(id)             rank 0: 128 bytes to hand to every rank out of band (ncclGetUniqueId)
+ *   uwspr_dist_init(ctx, rank, world, id)  collective: every rank calls it with the same id
+ *   uwspr_dist_gather(ctx, send, bytes, recv, root, UWSPR_DEVICE)
+ *        every rank contributes `bytes` bytes of device memory (equal on all ranks: pad the shards);
+ *        the root receives world * bytes in rank order (recv may be NULL elsewhere).  Asynchronous on
+ *        the context's stream, after whatever produced `send` there.
+ *   uwspr_dist_finalize(ctx)             (also done by uwspr_ctx_destroy) */
+int uwspr_dist_unique_id(void *id128);
+int uwspr_dist_init(uwspr_ctx *ctx, int rank, int world, const void *id128);
+int uwspr_dist_gather(uwspr_ctx *ctx, const void *send, size_t bytes, void *recv, int root, int where);
+int uwspr_dist_finalize(uwspr_ctx *ctx);
+
 /* ---- pipelined end-to-end decoder ---------------------------------------------------------- */
 /* The whole receive chain of examples/WaveFilePlusNoiseDecode.grc behind one object:
  *   sliding_window_stream_to_pdu (lib/sliding_window_stream_to_pdu_impl.cc:97-138)  -> frames in place

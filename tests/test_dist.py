@@ -88,3 +88,39 @@ def test_gather_is_identity_without_a_process_group():
     from gr_uwspr_amd import dist as D
     x = torch.arange(12, dtype=torch.uint8).reshape(3, 4)
     assert torch.equal(D.gather_slabs(x)[0], x)
+
+
+@pytest.mark.gpu
+def test_c_abi_gather_equals_the_torch_gather_on_one_rank(G, monkeypatch):
+    """uwspr_dist_*: the C-ABI gather (RCCL point-to-point transfers to the root) with one rank is the
+    identity, byte-equal to dist.gather_slabs; with UWSPR_DIST_FORCE_COMM=1 a real one-rank RCCL
+    communicator is created and destroyed in this process (dlopen + the eight entry points), next to
+    whatever collective library PyTorch brought."""
+    import torch
+    from gr_uwspr_amd import dist as D
+    frames = G.synth.make_frames(6, seed=77, snr_db=-18.0)
+    c = G.Context()
+    try:
+        dev = torch.from_numpy(frames).cuda()
+        cd = torch.empty(6 * c.maxfreqs * 48, dtype=torch.uint8, device="cuda")
+        nd = torch.empty(6, dtype=torch.int32, device="cuda")
+        od = torch.empty(6 * G.native.DEMOD_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        c.pipeline_batch_into(dev, cd, nd, od, max_per_frame=1)
+        slab = torch.zeros((6, D.SLAB_BYTES), dtype=torch.uint8, device="cuda")
+        c.pack_slabs_into(6, D.SLAB_K, slab)
+        c.synchronize()
+        want = D.gather_slabs(slab)                         # [1, 6, 416]
+        for force in ("0", "1"):
+            monkeypatch.setenv("UWSPR_DIST_FORCE_COMM", force)
+            uid = G.Context.dist_unique_id()
+            assert len(uid) == 128 and any(uid)
+            c.dist_init(0, 1, uid)
+            got = torch.zeros_like(slab)
+            c.dist_gather(slab, got, root=0)
+            c.synchronize()
+            assert torch.equal(got.view(1, 6, D.SLAB_BYTES), want)
+            c.dist_finalize()
+        with pytest.raises(G.UwsprError):
+            c.dist_gather(slab, slab, root=0)                # not initialised
+    finally:
+        c.close()
