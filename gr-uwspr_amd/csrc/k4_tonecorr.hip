@@ -53,7 +53,35 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int T>
+// The correlation step (cc:206-207) and the phasor rotation (cc:193-195).  FAST = false is the
+// reference's arithmetic: every product and every sum rounded on its own, left to right.  FAST = true
+// (UWSPR_FAST_SEARCH=1, stages S0..S4 only, never the soft symbols) contracts them into fused
+// multiply-adds: half the instructions, one rounding per product-sum -- metrics agree to ~1e-6 relative,
+// which may move an argmax at a near-tie (tools/fast_search_eval.py measures how often).
+template <bool FAST>
+__device__ __forceinline__ void k4_mac(float &inp, float &quad, float xx, float xy, float c, float s) {
+  if (FAST) {
+    inp = __builtin_fmaf(xy, s, __builtin_fmaf(xx, c, inp));
+    quad = __builtin_fmaf(xy, c, __builtin_fmaf(-xx, s, quad));
+  } else {
+    inp = (inp + xx * c) + xy * s;     // cc:206
+    quad = (quad - xx * s) + xy * c;   // cc:207
+  }
+}
+template <bool FAST>
+__device__ __forceinline__ void k4_rot(float &c, float &s, float cd, float sd) {
+  float nc, ns;
+  if (FAST) {
+    nc = __builtin_fmaf(c, cd, -(s * sd));
+    ns = __builtin_fmaf(c, sd, s * cd);
+  } else {
+    nc = c * cd - s * sd;              // cc:193-195
+    ns = c * sd + s * cd;
+  }
+  c = nc; s = ns;
+}
+
+template <int T, bool FAST = false>
 __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
     const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_hyp *__restrict__ hyps,
     int H, float *__restrict__ p_out) {
@@ -172,13 +200,8 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
         const float xx = half ? v.z : v.x, xy = half ? v.w : v.y;
 #pragma unroll
         for (int j = 0; j < T; j++) {
-          // cc:206-207, left to right
-          inp[j] = (inp[j] + xx * c[j]) + xy * s[j];
-          quad[j] = (quad[j] - xx * s[j]) + xy * c[j];
-          // cc:193-195
-          const float nc = c[j] * cd[j] - s[j] * sd[j];
-          const float ns = c[j] * sd[j] + s[j] * cd[j];
-          c[j] = nc; s[j] = ns;
+          k4_mac<FAST>(inp[j], quad[j], xx, xy, c[j], s[j]);   // cc:206-207, left to right
+          k4_rot<FAST>(c[j], s[j], cd[j], sd[j]);              // cc:193-195
         }
       }
     }
@@ -217,7 +240,8 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   dim3 blk(64 * K4_WAVES);
-  if (T == 1) launch_timed(c, ps, k4_tonecorr<1>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po);
+  if (T == 1 && c->fast_now) launch_timed(c, ps, (k4_tonecorr<1, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po);
+  else if (T == 1) launch_timed(c, ps, k4_tonecorr<1>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po);
   else if (T == 2) launch_timed(c, ps, k4_tonecorr<2>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po);
   else launch_timed(c, ps, k4_tonecorr<4>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po);
 }
@@ -249,7 +273,7 @@ __device__ unsigned long long g_k4_stamps[K4_STAMP_WAVES * 4];
 #define K4_STAMP(slot) do { } while (0)
 #endif
 
-template <int NL>
+template <int NL, bool FAST = false>
 __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
     const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_grp *__restrict__ grps,
     int G, float *__restrict__ p_out) {
@@ -417,13 +441,8 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
     for (int k = 0; k < 16; k++) {
       if (k < 15) read_slot(k + 1, xn);
 #pragma unroll
-      for (int l = 0; l < NLW; l++) {
-        inp[l] = (inp[l] + xc[l].x * c) + xc[l].y * s;     // cc:206
-        quad[l] = (quad[l] - xc[l].x * s) + xc[l].y * c;   // cc:207
-      }
-      const float nc = c * cd - s * sd;                    // cc:193-195
-      const float ns = c * sd + s * cd;
-      c = nc; s = ns;
+      for (int l = 0; l < NLW; l++) k4_mac<FAST>(inp[l], quad[l], xc[l].x, xc[l].y, c, s);   // cc:206-207
+      k4_rot<FAST>(c, s, cd, sd);                          // cc:193-195
 #pragma unroll
       for (int l = 0; l < NLP; l++) xc[l] = xn[l];
     }
@@ -466,7 +485,8 @@ void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   dim3 blk(64 * K4G_WAVES);
-  if (NL == 5) launch_timed(c, ps, k4_group<5>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
+  if (NL == 5 && c->fast_now) launch_timed(c, ps, (k4_group<5, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
+  else if (NL == 5) launch_timed(c, ps, k4_group<5>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
   else if (NL == 6) launch_timed(c, ps, k4_group<6>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
   else launch_timed(c, ps, k4_group<8>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
 }
@@ -482,7 +502,7 @@ void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_
 // slot (c + q) mod M, column r with (q, r) = divmod(k + STEP l, 16) known at
 // compile time; the M slot addresses rotate once per chunk.  Arithmetic per
 // accumulator is exactly k4_group's (cc:193-195, 206-207).
-template <int NL, int STEP>
+template <int NL, int STEP, bool FAST = false>
 __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
     const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_grp *__restrict__ grps,
     int G, float *__restrict__ p_out) {
@@ -646,12 +666,9 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
           for (int l = 0; l < NL; l++) {
             if (SKIP && l == 2) continue;
             const float xx = half ? vc[l].z : vc[l].x, xy = half ? vc[l].w : vc[l].y;
-            inp[l] = (inp[l] + xx * c) + xy * s;     // cc:206
-            quad[l] = (quad[l] - xx * s) + xy * c;   // cc:207
+            k4_mac<FAST>(inp[l], quad[l], xx, xy, c, s);   // cc:206-207
           }
-          const float nc = c * cd - s * sd;          // cc:193-195
-          const float ns = c * sd + s * cd;
-          c = nc; s = ns;
+          k4_rot<FAST>(c, s, cd, sd);                // cc:193-195
         }
 #pragma unroll
         for (int l = 0; l < NL; l++) vc[l] = vn[l];
@@ -703,7 +720,8 @@ void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_gr
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   dim3 blk(64 * K4G_WAVES);
-  if (r5) launch_timed(c, ps, (k4_ring<5, 16>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
+  if (r5 && c->fast_now) launch_timed(c, ps, (k4_ring<5, 16, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
+  else if (r5) launch_timed(c, ps, (k4_ring<5, 16>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
   else launch_timed(c, ps, (k4_ring<6, 8>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
 }
 
@@ -732,7 +750,7 @@ constexpr int K4F_PAIRS = 54;   // symbols per workgroup: 162 = 3 x 54
 #define K4F_CHUNK 32
 #endif
 
-template <int NF, int CH>   // CH = samples per staged chunk (16 or 32)
+template <int NF, int CH, bool FAST = false>   // CH = samples per staged chunk (16 or 32)
 __global__ __launch_bounds__(256) void k4_fstage(
     const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_hyp *__restrict__ hyps,
     int nslots, float *__restrict__ p_out) {
@@ -831,9 +849,7 @@ __global__ __launch_bounds__(256) void k4_fstage(
 #pragma unroll
           for (int k = 0; k < CH; k++) {
             reinterpret_cast<float2 *>(&tab[tone][k >> 1][lane])[k & 1] = make_float2(cq, sq);
-            const float nc = cq * cdq - sq * sdq;   // cc:193-195
-            const float ns = cq * sdq + sq * cdq;
-            cq = nc; sq = ns;
+            k4_rot<FAST>(cq, sq, cdq, sdq);         // cc:193-195
           }
         }
         __syncthreads();
@@ -846,10 +862,8 @@ __global__ __launch_bounds__(256) void k4_fstage(
           for (int q = 0; q < NF; q++) {
             if (SKIP && q == NF / 2) continue;
             const float4 ph = tab[tone][k >> 1][q];   // same address in every lane: LDS broadcast
-            inp[q] = (inp[q] + x.x * ph.x) + x.y * ph.y;      // cc:206, step k
-            quad[q] = (quad[q] - x.x * ph.y) + x.y * ph.x;    // cc:207
-            inp[q] = (inp[q] + x.z * ph.z) + x.w * ph.w;      // step k + 1
-            quad[q] = (quad[q] - x.z * ph.w) + x.w * ph.z;
+            k4_mac<FAST>(inp[q], quad[q], x.x, x.y, ph.x, ph.y);      // cc:206-207, step k
+            k4_mac<FAST>(inp[q], quad[q], x.z, x.w, ph.z, ph.w);      // step k + 1
           }
         }
       }
@@ -879,11 +893,8 @@ __global__ __launch_bounds__(256) void k4_fstage(
           const float xx = half ? x4.z : x4.x, xy = half ? x4.w : x4.y;
 #pragma unroll
           for (int q = 0; q < NF; q++) {
-            inp[q] = (inp[q] + xx * c[q]) + xy * s[q];        // cc:206
-            quad[q] = (quad[q] - xx * s[q]) + xy * c[q];      // cc:207
-            const float nc = c[q] * cd[q] - s[q] * sd[q];     // cc:193-195
-            const float ns = c[q] * sd[q] + s[q] * cd[q];
-            c[q] = nc; s[q] = ns;
+            k4_mac<FAST>(inp[q], quad[q], xx, xy, c[q], s[q]);        // cc:206-207
+            k4_rot<FAST>(c[q], s[q], cd[q], sd[q]);                  // cc:193-195
           }
         }
       }
@@ -904,8 +915,12 @@ void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_
                             int64_t nhyps, float4 *p) {
   if (nslots <= 0) return;
   prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
-  launch_timed(c, ps, (k4_fstage<5, K4F_CHUNK>), dim3(3u * (unsigned)nslots), dim3(256), 0,
-               (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p);
+  if (c->fast_now)
+    launch_timed(c, ps, (k4_fstage<5, K4F_CHUNK, true>), dim3(3u * (unsigned)nslots), dim3(256), 0,
+                 (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p);
+  else
+    launch_timed(c, ps, (k4_fstage<5, K4F_CHUNK>), dim3(3u * (unsigned)nslots), dim3(256), 0,
+                 (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p);
 }
 
 }  // namespace uwspr

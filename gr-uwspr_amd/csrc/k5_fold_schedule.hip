@@ -531,9 +531,34 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
 
 // Fold of a candidate's NIN hypotheses (one wavefront each) fused with the
 // schedule transition that consumes them: one workgroup per candidate slot.
+// UWSPR_FAST_SEARCH=1, stages S0..S4: the per-hypothesis metric by wavefront shuffle-tree sums -- each lane
+// adds its (up to three) symbols' terms, then six butterfly steps; a different summation ORDER than
+// cc:213-215, so the metric agrees with the reference only to rounding (~1e-6 relative).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float fold_wave_fast(const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p, int h) {
+  const int lane = threadIdx.x & 63;
+  if (hyps[h].frame < 0) return -1e30f;
+  float tp = 0.0f, sm = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int i = lane + 64 * r;
+    if (i < UWSPR_NSYM) {
+      const float4 P = p[(size_t)h * UWSPR_NSYM + i];
+      tp += (P.x + P.y) + (P.z + P.w);
+      const float cmet = (P.y + P.w) - (P.x + P.z);
+      sm += pr3_rt(i) ? cmet : -cmet;
+    }
+  }
+  return ieee_divf(wave_sum(sm), wave_sum(tp));
+}
+
 // LDS: the folds go through LDS (fold_wave) or registers (fold_wave_rl).  ONEWAVE: one wavefront folds the
 // slot's hypotheses one after the other (5 KB of LDS per workgroup instead of 26 KB).
-template <int STAGE, bool LDS, bool ONEWAVE>
+template <int STAGE, bool LDS, bool ONEWAVE, bool FAST = false>
 __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__restrict__ hin,
                              const float4 *__restrict__ p, float *__restrict__ sync,
                              dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
@@ -549,6 +574,7 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
     // a hypothesis marked known (frame <= -2) repeats the previous winner: its metric is in the state
     float s;
     if (hin[h].frame <= -2) s = state[slot].csync;
+    else if (FAST) s = fold_wave_fast(hin, p, h);
     else if (LDS) s = fold_wave<false>(hin, p, h, 50.0f, nullptr, L[(LDS && !ONEWAVE) ? q : 0], nullptr);
     else s = fold_wave_rl<false>(hin, p, h, 50.0f, nullptr);
     if ((threadIdx.x & 63) == 0) { sy[q] = s; sync[h] = s; }
@@ -651,7 +677,15 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots, int njig) {
                        c->d_cent, c->d_cent_frame, nslots, reuse, njig);
   };
   const bool one = c->k5_onewave;
-  if (c->use_k5_lds && !one) {
+  if (c->fast_now) {
+    switch (stage) {
+      case 1: go(k5_fold_step<1, false, false, true>, 320); break;
+      case 2: go(k5_fold_step<2, false, false, true>, 320); break;
+      case 3: go(k5_fold_step<3, false, false, true>, 128); break;
+      case 4: go(k5_fold_step<4, false, false, true>, 320); break;
+      default: go(k5_fold_step<5, false, false, true>, 320); break;
+    }
+  } else if (c->use_k5_lds && !one) {
     switch (stage) {
       case 1: go(k5_fold_step<1, true, false>, 320); break;
       case 2: go(k5_fold_step<2, true, false>, 320); break;

@@ -118,6 +118,9 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   // frequency/drift stages through the grid form: parity-tested but measured 9 % SLOWER than the
   // flat kernel at 5 hypotheses per candidate (4 waves/SIMD, window loads not overlapped): opt-in
   c->use_stage_grid = getenv("UWSPR_K4_STAGE_GRID") && atoi(getenv("UWSPR_K4_STAGE_GRID")) != 0;
+  c->fast_search = getenv("UWSPR_FAST_SEARCH") && atoi(getenv("UWSPR_FAST_SEARCH")) != 0;
+  c->fast_now = false;
+  if (c->fast_search) c->use_fused = false;   // the fast variant exists for the staged launches only
   c->cap_slab = 0; c->d_slab = nullptr;
   c->dist_comm = nullptr; c->dist_rank = 0; c->dist_world = 0;
   c->sched_grid = getenv("UWSPR_SCHED_GRID") ? atoi(getenv("UWSPR_SCHED_GRID")) : 0;
@@ -755,6 +758,7 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
   const bool lazy = njig < UWSPR_NJIG;   // only tries idt < njig of stage 5, packed njig per slot
   if (lazy && (rc = ensure(c, &c->d_pwin, &c->cap_pwin, nslots * UWSPR_NSYM * 4))) return rc;
   for (int s = 0; s < 6; s++) {
+    c->fast_now = c->fast_search && s < 5;   // S5 (the soft symbols) is always the reference's arithmetic
     const int H = (int)(nslots * (s == 5 ? njig : hpc[s]));
     const dev_hyp *h = half[s & 1];
     // lag sweeps (S0, S3, the 17 jiggered shifts) share their tone phasors
@@ -780,6 +784,7 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
     else launch_tonecorr(c, dframes, B, h, H, c->d_p);
     if (s < 5) {
       launch_fold_step(c, s + 1, (int)nslots, njig);   // fold of stage s + transition to stage s+1
+      c->fast_now = false;
     } else {
       launch_fold(c, h, c->d_p, H, c->d_sync, c->d_sym);
       launch_sched_finish(c, (int)nslots, njig);

@@ -146,6 +146,9 @@ struct uwspr_ctx {
   bool reuse_centre;     // skip the stage-winner hypothesis in S1/S3/S4 (UWSPR_K4_REUSE=0: recompute it)
   bool use_lag_ring;     // S3/S5 groups through the LDS-ring form (UWSPR_K4_RING=0: plain groups)
   bool use_k5_lds;       // wave folds through LDS (default); UWSPR_K5_LDS=0: the register / v_readlane form
+  // UWSPR_FAST_SEARCH=1: stages S0..S4 of the schedule with fused multiply-adds and shuffle-tree sums (not
+  // the reference's arithmetic; S5 and every other entry point stay exact).  fast_now: set around those launches.
+  bool fast_search, fast_now;
   bool k5_onewave;       // UWSPR_K5_ONEWAVE=1: one wavefront per slot folds its hypotheses in turn (5 KB LDS, not 26)
   // fused schedule (k6_sched: one workgroup per candidate runs S0..S5; UWSPR_SCHED_FUSED=0: staged launches)
   bool use_fused; bool sched_nopad; int sched_grid;
