@@ -324,6 +324,13 @@ def main():
 
     for i in range(args.warmup):
         step(lanes, i)
+    # warm up until two consecutive K-step regions agree within 2 % (clocks, caches, the lanes' rotation over
+    # the distinct batches: round 2's first timed repeat was 11 % below the others), at most 8 regions
+    warm_regions = []
+    for _ in range(8):
+        warm_regions.append(region(lanes, K, gather=False)[0])
+        if len(warm_regions) >= 2 and abs(warm_regions[-1] - warm_regions[-2]) <= 0.02 * warm_regions[-2]:
+            break
     # ---- the timed region, R times ----
     reps = []
     for _ in range(max(1, args.repeats)):
@@ -554,8 +561,17 @@ def main():
     result = None
     pmc = None
     tpath = os.path.join(ROOT, "profiles", "k4_traffic.json")
+    traffic_stale = None
     if os.path.exists(tpath):                 # PMC passes taken with rocprofv3 on this workload (tools/run_profiles.sh)
         pmc = json.load(open(tpath))
+        if pmc.get("library_sources_sha256") != N.source_digest():
+            # counters of ANOTHER build say nothing about this one: loud, and no figure rather than a stale one
+            traffic_stale = ("profiles/k4_traffic.json was taken on other sources (%s...) than this build (%s...): "
+                             "re-run tools/run_profiles.sh + tools/make_final_profile.sh"
+                             % (str(pmc.get("library_sources_sha256"))[:12], N.source_digest()[:12]))
+            if rank == 0:
+                print("WARNING: " + traffic_stale, file=sys.stderr)
+            pmc = None
     if rank == 0:
         k4_ms_step = k4["ms"] / n1
         k4_launch_ms = k4["ms"] / max(k4["launches"], 1)
@@ -572,6 +588,13 @@ def main():
             "ms_per_step": 1e3 * dt / K,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "chosen": {"sched": "fused" if fused else "staged", "streams": ns},
+            "single_stream": ({"frames_per_s": frames_per_step * K / min(v for (f, s_), v in trials.items() if s_ == 1),
+                               "sched": "fused" if min(((v, f) for (f, s_), v in trials.items() if s_ == 1))[1] else "staged",
+                               "note": "the same K-step region on ONE HIP stream (best schedule form); `value` overlaps "
+                                       "%d batches on %d streams" % (ns, ns)}
+                              if any(s_ == 1 for (_f, s_) in trials) else None),
+            "warmup_regions_until_stable": len(warm_regions),
             "repeats": {"n": len(reps), "frames_per_s": rates, "min": min(rates), "median": float(np.median(rates)),
                         "max": max(rates), "value_is": "median"},
             "config": {"workload": "BASELINE configs[%d]: %s synthetic .c2 frames (375 Hz, 45000 samples, SNR %.0f dB)"
@@ -597,6 +620,7 @@ def main():
                          "achieved": achieved_tops, "peak": FP32_NOFMA_PEAK_TOPS, "unit": "Top/s",
                          "frac": achieved_tops / FP32_NOFMA_PEAK_TOPS,
                          "traffic": pm.get("bytes_per_step"), "traffic_source": pm.get("source"),
+                         "traffic_stale": traffic_stale,
                          "valu_issue_utilisation_pmc": pm.get("valu_issue_utilisation"),
                          "ops_per_step_algorithmic": ops_step,
                          "kernel_ms_per_step": k4_ms_step, "avg_launch_ms": k4_launch_ms,

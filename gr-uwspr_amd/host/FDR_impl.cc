@@ -74,16 +74,23 @@ class FDR_impl : public FDR {
     const int B = (int)d_pending.size();
     if (B == 0) return;
     const size_t fbytes = (size_t)d_fl * 2 * sizeof(float);
-    std::shared_ptr<void> buf = take_buffer((size_t)B * fbytes);
-    float *dev = static_cast<float *>(buf.get());
     // Overlap-aware ingest (cc:113-135: consecutive PDUs share fl - hop samples): when the PDUs
     // carry consecutive stream positions only the samples the device has not seen are uploaded and
-    // the frames are cut there; otherwise the frames go up whole.
+    // the frames are cut there; otherwise the frames go up whole.  The hop is the distance between
+    // consecutive PDUs: within the batch, or -- one PDU per call, the default -- from the PDU before.
     bool streamed = d_pending[0]->stream_pos >= 0;
-    const long long hop = B > 1 ? d_pending[1]->stream_pos - d_pending[0]->stream_pos : d_hop;
+    const long long hop = B > 1 ? d_pending[1]->stream_pos - d_pending[0]->stream_pos
+                                : (d_last_pos >= 0 ? d_pending[0]->stream_pos - d_last_pos : d_hop);
     for (int b = 1; b < B && streamed; b++)
       streamed = d_pending[b]->stream_pos == d_pending[0]->stream_pos + b * hop;
     streamed = streamed && hop > 0 && hop <= d_fl;
+    d_last_pos = d_pending[B - 1]->stream_pos;
+    std::shared_ptr<void> buf;
+    float *dev = nullptr;
+    if (streamed) {            // a device batch buffer only when frames are going to be handed on in it
+      buf = take_buffer((size_t)B * fbytes);
+      dev = static_cast<float *>(buf.get());
+    }
     int rc = UWSPR_OK;
     if (streamed) {
       if (hop != d_hop || B > d_stream_frames) {
@@ -138,7 +145,7 @@ class FDR_impl : public FDR {
 
   uwspr_ctx *d_ctx;
   int d_fl, d_maxfreqs, d_batch;
-  long long d_hop = 0, d_next_pos = -1;
+  long long d_hop = 0, d_next_pos = -1, d_last_pos = -1;
   int d_stream_frames = 0;
   std::shared_ptr<dev_pool> d_pool = std::make_shared<dev_pool>();
   std::vector<std::shared_ptr<const samples_pdu> > d_pending;

@@ -64,6 +64,15 @@ def _digest(paths):
     return h.hexdigest()
 
 
+def source_digest():
+    """sha256 over the sources the product library is built from (what a profile taken with
+    tools/run_profiles.sh is valid for)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    deps.append(os.path.join(_HERE, "..", "include", "uwspr_hip.h"))
+    return _digest(deps)
+
+
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 every kernel + the C ABI into lib/libuwspr_hip.so,
     then the host block mirror (gr-uwspr_amd/host) into lib/libuwspr_blocks.so."""

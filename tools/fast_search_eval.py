@@ -16,6 +16,8 @@ PER, CH = 2, 300
 tot = dict(frames=0, cands=0, worth=0, same_search=0, shift_diff=0, f1_diff=0, drift_diff=0, worth_diff=0,
            sym_diff_given_same_search=0, dec_exact=0, dec_fast=0, dec_only_exact=0, dec_only_fast=0, msg_diff=0)
 max_rel = 0.0
+rels = []
+worst = None
 t_exact = t_fast = 0.0
 os.environ["UWSPR_SCHED_FUSED"] = "0"
 cx = G.Context()
@@ -47,7 +49,11 @@ while done < N:
             wd = int(a["worth_a_try"]) != int(f["worth_a_try"])
             tot["shift_diff"] += sd; tot["f1_diff"] += fd; tot["drift_diff"] += dd; tot["worth_diff"] += wd
             if a["sync1"] != 0:
-                max_rel = max(max_rel, abs(float(f["sync1"]) - float(a["sync1"])) / abs(float(a["sync1"])))
+                rel = abs(float(f["sync1"]) - float(a["sync1"])) / abs(float(a["sync1"]))
+                rels.append(rel)
+                if rel > max_rel:
+                    max_rel, worst = rel, {"sync1_exact": float(a["sync1"]), "sync1_fast": float(f["sync1"]), "snr_db": snr,
+                                           "worth_a_try": int(a["worth_a_try"])}
             if not (sd or fd or dd or wd):
                 tot["same_search"] += 1
                 tot["sym_diff_given_same_search"] += int(a["symbols"].tobytes() != f["symbols"].tobytes())
@@ -61,6 +67,9 @@ while done < N:
         print("...", done, "frames", flush=True)
 cx.close(); cf.close()
 tot["sync1_max_rel_err"] = max_rel
+rels = np.array(rels)
+tot["sync1_rel_err"] = {"median": float(np.median(rels)), "p99": float(np.quantile(rels, 0.99)), "p999": float(np.quantile(rels, 0.999)),
+                        "above_1e-5": int((rels > 1e-5).sum()), "of": int(rels.size), "worst": worst}
 tot["host_call_seconds_exact_fast"] = [t_exact, t_fast]
 print(json.dumps(tot, indent=1))
 os.makedirs("gpurun_out", exist_ok=True)

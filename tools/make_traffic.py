@@ -58,6 +58,9 @@ def main():
             "source": "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU GRBM_GUI_ACTIVE passes)" % src,
         }
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import gr_uwspr_amd as G
+    out["library_sources_sha256"] = G.native.source_digest()   # bench.py refuses the figures for any other build
     json.dump(out, open(os.path.join(root, "profiles", "k4_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
