@@ -85,10 +85,11 @@ def test_receive_flowgraph_decodes_ve3emb(exe):
 
 @pytest.mark.gpu
 def test_stream_ingest_and_device_hand_over_equal_whole_frame_calls(exe):
-    """next-2: an 8-frame stream through framer -> FDR -> sync_and_demodulate -> unpacker.  Batched
-    (4 PDUs per device call) the FDR mirror uploads every sample once (uwspr_stream_*) and hands
-    its device-resident frames to sync_and_demodulate; one PDU per call everything is uploaded
-    whole.  Same candidates (to the last digit printed) and the same decodes either way."""
+    """next-2: an 8-frame stream through framer -> FDR -> sync_and_demodulate -> unpacker.  The FDR
+    mirror uploads every sample once (uwspr_stream_*) and hands its device-resident frames to
+    sync_and_demodulate -- batched (4 PDUs per device call) from the first PDU on, one PDU per call
+    (the default) from the second on (the hop is then the distance to the PDU before; the first frame
+    goes up whole).  Same candidates (to the last digit printed) and the same decodes either way."""
     r = subprocess.run([exe, "stream", os.path.join(GOLDEN, "VE3EMB.c2")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = r.stdout.split("\n")
@@ -97,7 +98,7 @@ def test_stream_ingest_and_device_hand_over_equal_whole_frame_calls(exe):
     assert p0 == p1 and len(p0) >= 8
     assert "pass 0 pdus 8" in r.stdout and "pass 1 pdus 8" in r.stdout
     assert any(l.startswith("pass 0 frames") and l.endswith("on_device 8") for l in lines)
-    assert any(l.startswith("pass 1 frames") and l.endswith("on_device 0") for l in lines)
+    assert any(l.startswith("pass 1 frames") and l.endswith("on_device 7") for l in lines)
     assert sum("text VE3EMB FN25 30" in l for l in p0) >= 2
 
 
