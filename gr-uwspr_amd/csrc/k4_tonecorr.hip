@@ -753,7 +753,7 @@ constexpr int K4F_PAIRS = 54;   // symbols per workgroup: 162 = 3 x 54
 template <int NF, int CH, bool FAST = false>   // CH = samples per staged chunk (16 or 32)
 __global__ __launch_bounds__(256) void k4_fstage(
     const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_hyp *__restrict__ hyps,
-    int nslots, float *__restrict__ p_out) {
+    int nslots, float *__restrict__ p_out, int onegen) {
   constexpr int K4F_ROWDW = 2 * CH + 4;   // dwords per staged row: CH samples x 8 B + 16 B pad (16-byte aligned)
   constexpr int NCH = 256 / CH;           // chunks per symbol
   constexpr int SEGS = 256 / CH;          // symbols staged per loader round
@@ -825,17 +825,25 @@ __global__ __launch_bounds__(256) void k4_fstage(
   for (int q = 0; q < NF; q++) { inp[q] = 0.0f; quad[q] = 0.0f; }
 
   if (tabled) {
-    // lanes 0..NF-1 of each wave own the recurrence of (frequency = lane, this wave's tone)
+    // The NF x 4 recurrences (frequency, tone) of the workgroup all run on lanes 0..4 NF - 1 of wavefront 0:
+    // a recurrence step costs the wavefront that runs it six instruction slots however few lanes are
+    // active, so one wavefront generating every tone's table (instead of each wavefront its own tone's)
+    // takes 3/4 of that overhead out (-2 % of the whole step's VALU instructions).
     float cq = 1.0f, sq = 0.0f, cdq = 1.0f, sdq = 0.0f;
-    if (lane < NF) {
+    // (onegen == 0, UWSPR_K4F_ONEGEN=0: every wavefront generates its own tone's NF tables -- same values)
+    const int gq = onegen ? lane % NF : min(lane, NF - 1);              // this lane's (frequency, tone) as a generator
+    const int gt = onegen ? min(lane / NF, 3) : tone;
+    const bool gen = onegen ? (tone == 0) && (lane < 4 * NF) : (lane < NF);
+    if (gen) {
       float fq = f0[0];
 #pragma unroll
-      for (int q = 1; q < NF; q++) fq = (lane == q) ? f0[q] : fq;
+      for (int q = 1; q < NF; q++) fq = (gq == q) ? f0[q] : fq;
       const float fp = (h0.m_type == UWSPR_LINEAR)
                            ? (float)((double)fq + ((double)h0.drift / 2.0) * ((double)(float)0 - 81.0) / 81.0)
                            : fq + h0.slmc;                                   // cc:173 / cc:179 (drift == 0)
+      const float gdelta = ((float)gt - 1.5f) * 1.46484375f;                 // cc:148
       double sn, cs;
-      sincos(kTwoPiDt * (double)(fp + delta), &sn, &cs);
+      sincos(kTwoPiDt * (double)(fp + gdelta), &sn, &cs);
       cdq = (float)cs;
       sdq = (float)sn;
     }
@@ -845,10 +853,10 @@ __global__ __launch_bounds__(256) void k4_fstage(
       for (int ch = 0; ch < NCH; ch++) {
         __syncthreads();              // the previous chunk has been read by everyone
         store_chunk();
-        if (lane < NF) {
+        if (gen) {
 #pragma unroll
           for (int k = 0; k < CH; k++) {
-            reinterpret_cast<float2 *>(&tab[tone][k >> 1][lane])[k & 1] = make_float2(cq, sq);
+            reinterpret_cast<float2 *>(&tab[gt][k >> 1][gq])[k & 1] = make_float2(cq, sq);
             k4_rot<FAST>(cq, sq, cdq, sdq);         // cc:193-195
           }
         }
@@ -917,10 +925,10 @@ void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_
   prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
   if (c->fast_now)
     launch_timed(c, ps, (k4_fstage<5, K4F_CHUNK, true>), dim3(3u * (unsigned)nslots), dim3(256), 0,
-                 (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p);
+                 (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p, c->k4f_onegen ? 1 : 0);
   else
     launch_timed(c, ps, (k4_fstage<5, K4F_CHUNK>), dim3(3u * (unsigned)nslots), dim3(256), 0,
-                 (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p);
+                 (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p, c->k4f_onegen ? 1 : 0);
 }
 
 }  // namespace uwspr
