@@ -535,7 +535,8 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   // nvalid bit 8: lag slot 2 repeats the previous stage's winner, its metric is known and nobody
   // reads its p[] -- skipped when that holds for every live group of the wave (NL == 5 only)
   const bool knownA = !okA || (A.nvalid & 0x100) != 0, knownB = !okB || (Bg.nvalid & 0x100) != 0;
-  const bool skip_mid = (NL == 5) && knownA && (knownB || sb >= PPW);
+  // (NL == 6, the jiggered shifts: the middle group's lag slot 2 is try 0, known when it repeats the stage-4 winner)
+  const bool skip_mid = (NL == 5 || NL == 6) && knownA && (knownB || sb >= PPW);
   // first lag of the two groups; skipped groups point at safe samples
   const int l0A = okA ? A.lag[0] : 1 - 256 * iA0;
   const int l0B = okB ? Bg.lag[0] : 1;

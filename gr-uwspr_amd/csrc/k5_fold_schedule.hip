@@ -123,24 +123,28 @@ struct k5_wave_lds_soft {
 };
 
 // One wavefront folds hypothesis h; returns its sync metric in every lane.
+// prow: the hypothesis' 162 tone magnitudes, or null = p + 162 h.  (A mode-2 hypothesis marked known --
+// frame <= -2: try 0 of stage 5 repeating the stage-4 winner -- is folded from the magnitudes the schedule
+// kept for it; see k5_fold_wave.)
 template <bool SOFT>
 __device__ __forceinline__ float fold_wave(const dev_hyp *__restrict__ hyps,
                                            const float4 *__restrict__ p, int h, float symfac,
                                            uint8_t *__restrict__ symbols, k5_wave_lds &L,
-                                           k5_wave_lds_soft *Q) {
+                                           k5_wave_lds_soft *Q, const float4 *__restrict__ prow = nullptr) {
   const int lane = threadIdx.x & 63;
-  if (hyps[h].frame < 0) {
+  if (hyps[h].frame < 0 && !prow) {
     if (SOFT)
       for (int i = lane; i < UWSPR_NSYM; i += 64) symbols[(size_t)h * UWSPR_NSYM + i] = 0;
     return -1e30f;
   }
+  const float4 *src = prow ? prow : p + (size_t)h * UWSPR_NSYM;
   float fs[3];
 #pragma unroll
   for (int r = 0; r < 3; r++) {
     const int i = lane + 64 * r;
     fs[r] = 0.0f;
     if (i < UWSPR_NSYM) {
-      const float4 P = p[(size_t)h * UWSPR_NSYM + i];
+      const float4 P = src[i];
       const bool bit = pr3_rt(i);
       L.str[0][i] = P;
       const float cmet = (P.y + P.w) - (P.x + P.z);   // cc:214
@@ -208,13 +212,15 @@ __device__ __forceinline__ double rl_d(double v, int l) {
 
 template <bool SOFT>
 __device__ __forceinline__ float fold_wave_rl(const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p,
-                                              int h, float symfac, uint8_t *__restrict__ symbols) {
+                                              int h, float symfac, uint8_t *__restrict__ symbols,
+                                              const float4 *__restrict__ prow = nullptr) {
   const int lane = threadIdx.x & 63;
-  if (hyps[h].frame < 0) {
+  if (hyps[h].frame < 0 && !prow) {
     if (SOFT)
       for (int i = lane; i < UWSPR_NSYM; i += 64) symbols[(size_t)h * UWSPR_NSYM + i] = 0;
     return -1e30f;
   }
+  const float4 *src = prow ? prow : p + (size_t)h * UWSPR_NSYM;
   float4 P[3];
   float cm[3], fs[3];
   double q0[3], q1[3];
@@ -223,7 +229,7 @@ __device__ __forceinline__ float fold_wave_rl(const dev_hyp *__restrict__ hyps, 
     const int i = lane + 64 * r;
     P[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); cm[r] = 0.0f; fs[r] = 0.0f; q0[r] = 0.0; q1[r] = 0.0;
     if (i < UWSPR_NSYM) {
-      P[r] = p[(size_t)h * UWSPR_NSYM + i];
+      P[r] = src[i];
       const bool bit = pr3_rt(i);
       const float cmet = (P[r].y + P[r].w) - (P[r].x + P[r].z);   // cc:214
       cm[r] = bit ? cmet : -cmet;                                  // ss -/+ cmet == ss + (-/+cmet)
@@ -268,45 +274,51 @@ __device__ __forceinline__ float fold_wave_rl(const dev_hyp *__restrict__ hyps, 
   return sync;
 }
 
+// pwin / per_slot (stage 5 of the schedule, else null): hypothesis h belongs to slot h / per_slot; one marked
+// known (frame <= -2) repeats the stage-4 winner and is folded from pwin[slot] (its magnitudes, carried)
 template <bool SOFT>
 __global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave_rl(
     const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p, int H, float symfac,
-    float *__restrict__ sync, uint8_t *__restrict__ symbols) {
+    float *__restrict__ sync, uint8_t *__restrict__ symbols, const float4 *__restrict__ pwin, int per_slot) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = blockIdx.x * K5W_WAVES + wv;
   if (h >= H) return;  // wave-uniform
-  const float s = fold_wave_rl<SOFT>(hyps, p, h, symfac, symbols);
+  const float4 *prow = (pwin && hyps[h].frame <= -2) ? pwin + (size_t)(h / per_slot) * UWSPR_NSYM : nullptr;
+  const float s = fold_wave_rl<SOFT>(hyps, p, h, symfac, symbols, prow);
   if ((threadIdx.x & 63) == 0) sync[h] = s;
 }
 
 template <bool SOFT>
 __global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave(
     const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p, int H, float symfac,
-    float *__restrict__ sync, uint8_t *__restrict__ symbols) {
+    float *__restrict__ sync, uint8_t *__restrict__ symbols, const float4 *__restrict__ pwin, int per_slot) {
   __shared__ k5_wave_lds L[K5W_WAVES];
   __shared__ k5_wave_lds_soft Q[SOFT ? K5W_WAVES : 1];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = blockIdx.x * K5W_WAVES + wv;
   if (h >= H) return;  // wave-uniform
-  const float s = fold_wave<SOFT>(hyps, p, h, symfac, symbols, L[wv], SOFT ? &Q[wv] : nullptr);
+  const float4 *prow = (pwin && hyps[h].frame <= -2) ? pwin + (size_t)(h / per_slot) * UWSPR_NSYM : nullptr;
+  const float s = fold_wave<SOFT>(hyps, p, h, symfac, symbols, L[wv], SOFT ? &Q[wv] : nullptr, prow);
   if ((threadIdx.x & 63) == 0) sync[h] = s;
 }
 
 void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, float *sync,
-                 uint8_t *symbols) {
+                 uint8_t *symbols, const float4 *pwin, int per_slot) {
   if (H <= 0) return;
   prof_scope ps(c, UWSPR_K_FOLD, H);
-  // lanes form from 32768 hypotheses up (UWSPR_K5_LANES=0/1 forces one or the other)
+  // lanes form from 32768 hypotheses up (UWSPR_K5_LANES=0/1 forces one or the other); the schedule's
+  // stage 5 (carried magnitudes for the known try) always takes the wave form
   static const int forced = getenv("UWSPR_K5_LANES") ? atoi(getenv("UWSPR_K5_LANES")) : -1;
-  const bool lanes_form = forced >= 0 ? forced != 0 : H >= 32768;
+  const bool lanes_form = !pwin && (forced >= 0 ? forced != 0 : H >= 32768);
+  if (per_slot < 1) per_slot = 1;
   if (!lanes_form) {
     dim3 g((H + K5W_WAVES - 1) / K5W_WAVES), b(64 * K5W_WAVES);
     if (c->use_k5_lds) {
-      if (symbols) hipLaunchKernelGGL(k5_fold_wave<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
-      else hipLaunchKernelGGL(k5_fold_wave<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
+      if (symbols) hipLaunchKernelGGL(k5_fold_wave<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols, pwin, per_slot);
+      else hipLaunchKernelGGL(k5_fold_wave<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols, pwin, per_slot);
     } else {
-      if (symbols) hipLaunchKernelGGL(k5_fold_wave_rl<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
-      else hipLaunchKernelGGL(k5_fold_wave_rl<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols);
+      if (symbols) hipLaunchKernelGGL(k5_fold_wave_rl<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols, pwin, per_slot);
+      else hipLaunchKernelGGL(k5_fold_wave_rl<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols, pwin, per_slot);
     }
   } else {
     hipLaunchKernelGGL(k5_fold, dim3((H + 63) / 64), dim3(64), 0, c->stream, hyps, p, H, 50.0f,
@@ -378,11 +390,11 @@ __device__ inline void emit_centre(uwspr_candidate *ce, int32_t *cframe, const c
 }
 
 // cc:227-231 over a list scanned in order: strict >, defaults -1e30 / 0 / 0.0
-struct best3 { float sync; int shift; float f; };
+struct best3 { float sync; int shift; float f; int q; };   // q: the winning hypothesis, -1 = none won
 __device__ inline best3 best_of(const float *sy, const dev_hyp *hy, int n) {
-  best3 b{-1e30f, 0, 0.0f};
+  best3 b{-1e30f, 0, 0.0f, -1};
   for (int q = 0; q < n; q++)
-    if (sy[q] > b.sync) { b.sync = sy[q]; b.shift = hy[q].lag; b.f = hy[q].f0; }
+    if (sy[q] > b.sync) { b.sync = sy[q]; b.shift = hy[q].lag; b.f = hy[q].f0; b.q = q; }
   return b;
 }
 
@@ -432,7 +444,12 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
                                                 dev_grp *__restrict__ grps,
                                                 uwspr_candidate *__restrict__ cent,
                                                 int32_t *__restrict__ cframe, bool reuse, int team = 0,
-                                                int njig = UWSPR_NJIG) {
+                                                int njig = UWSPR_NJIG, int *wsrc = nullptr) {
+  // *wsrc (written by team 0): the input hypothesis whose tone magnitudes are now those of the state's
+  // (f1, shift1, drift1) -- the stage winner -- or -1: the winner is the hypothesis that was marked known
+  // (its magnitudes are the ones already kept) or nobody won.  The workgroup copies them to the slot's kept
+  // row, so that try 0 of stage 5 (which repeats the stage-4 winner) is never correlated again.
+  int ws = -1;
   // team (stage 5 only): lanes 0..19 of the first wavefront all derive the same new state, in
   // lockstep, and share the emission -- lane t < 17 writes try t, lanes 17..19 the lag groups
   cand_state st = state[slot];
@@ -446,7 +463,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
 
   if (STAGE == 1) {
     // after S0 (mode 0) -> S1 (cc:416-419): mode 1, f = f1 + ifreq*0.25, lag = shift1
-    if (live) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
+    if (live) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; ws = b.q; }
     // q = 2 is (f1 + 0, shift1, drift1): the S0 hypothesis that just won (if one did)
     st.cknown = (reuse && live && st.sync1 > -1e30f) ? 1 : 0;
     st.csync = st.sync1;
@@ -455,7 +472,10 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     emit_centre(&cent[slot], &cframe[slot], st, live);
   } else if (STAGE == 2) {
     // after S1 -> S2 (cc:423-433): linear only, drift1 +- 0.5 at (f1, shift1)
-    if (live) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
+    if (live) {
+      best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f;
+      ws = (b.q == 2 && hi[2].frame <= -2) ? -1 : b.q;
+    }
     st.cknown = (reuse && live && st.sync1 > -1e30f) ? 1 : 0;   // (f1, shift1, drift1) has metric sync1
     st.csync = st.sync1;
     const bool lin = live && st.m_type == UWSPR_LINEAR;
@@ -473,8 +493,8 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
       float syncp = -1e30f, syncm = -1e30f;
       if (sy[0] > syncp) syncp = sy[0]; else { st.f1 = 0.0f; st.shift1 = 0; st.cknown = 0; }
       if (sy[1] > syncm) syncm = sy[1]; else { st.f1 = 0.0f; st.shift1 = 0; st.cknown = 0; }
-      if (syncp > st.sync1) { st.drift1 = st.driftp; st.sync1 = syncp; }
-      else if (syncm > st.sync1) { st.drift1 = st.driftm; st.sync1 = syncm; }
+      if (syncp > st.sync1) { st.drift1 = st.driftp; st.sync1 = syncp; ws = 0; }
+      else if (syncm > st.sync1) { st.drift1 = st.driftm; st.sync1 = syncm; ws = 1; }
     }
     st.worth = (live && st.sync1 > 0.10f) ? 1 : 0;
     // q = 2 is (f1, shift1, drift1): the winner of S1, or of S2 when a drift try beat it
@@ -489,7 +509,10 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     if (st.cknown) grps[slot].nvalid |= 0x100;   // lag slot 2 is known: K4 skips it
   } else if (STAGE == 4) {
     // after S3 -> S4 (cc:449-452): f = f1 + ifreq*0.05
-    if (st.worth) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
+    if (st.worth) {
+      best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f;
+      ws = (b.q == 2 && hi[2].frame <= -2) ? -1 : b.q;
+    }
     st.cknown = (reuse && st.worth && st.sync1 > -1e30f) ? 1 : 0;   // q = 2 repeats the S3 winner
     st.csync = st.sync1;
     for (int q = 0; q < 5; q++)
@@ -498,13 +521,20 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     emit_centre(&cent[slot], &cframe[slot], st, st.worth != 0);
   } else {
     // after S4 -> S5 (cc:457-468): 17 jiggered shifts, mode 2
-    if (st.worth) { best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f; }
+    if (st.worth) {
+      best3 b = best_of(sy, hi, 5); st.sync1 = b.sync; st.shift1 = b.shift; st.f1 = b.f;
+      ws = (b.q == 2 && hi[2].frame <= -2) ? -1 : b.q;
+    }
+    // try 0 is (f1, shift1, drift1): the hypothesis that just won stage 4 (cc:457-463 with idt = 0) -- known
+    // when one did: its magnitudes are the kept ones, K4 leaves it out, the fold reads the kept row
+    const bool known0 = reuse && st.worth && st.sync1 > -1e30f;
+    st.cknown = known0 ? 1 : 0;
     if (team < njig) {
       const int idt = team;
       int ii = (idt + 1) / 2;
       if (idt % 2 == 1) ii = -ii;
       ii = 8 * ii;
-      emit(&ho[idt], st, st.worth != 0, st.shift1 + ii, st.f1, st.drift1);
+      emit(&ho[idt], st, st.worth != 0, st.shift1 + ii, st.f1, st.drift1, idt == 0 && known0);
     }
     // The 17 jiggered shifts as three lag groups of 6, 6, 5 with ASCENDING, evenly spaced
     // lags (shift1 - 64 + 8 m, m = 0..16), so that a group's windows overlap and K4 can keep
@@ -524,9 +554,10 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
       for (int l = 0; l < n; l++) hmap |= (uint32_t)(id[l] - idt0) << (4 * l);
       emit_group(&grps[slot * 3 + g], st, st.worth != 0 && njig >= UWSPR_NJIG, st.f1, st.drift1,
                  slot * UWSPR_NJIG + idt0, gl, n, hmap);
+      if (g == 1 && known0) grps[slot * 3 + g].nvalid |= 0x100;   // its lag slot 2 (m = 8) is try 0: known
     }
   }
-  if (team == 0) state[slot] = st;
+  if (team == 0) { state[slot] = st; if (wsrc) *wsrc = ws; }
 }
 
 // Fold of a candidate's NIN hypotheses (one wavefront each) fused with the
@@ -563,10 +594,11 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
                              const float4 *__restrict__ p, float *__restrict__ sync,
                              dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
                              uwspr_candidate *__restrict__ cent, int32_t *__restrict__ cframe, int nslots,
-                             int reuse, int njig) {
+                             int reuse, int njig, float4 *__restrict__ pwin) {
   constexpr int NIN = STAGE == 3 ? 2 : 5;
   __shared__ k5_wave_lds L[LDS ? (ONEWAVE ? 1 : NIN) : 1];
   __shared__ float sy[NIN];
+  __shared__ int s_wsrc;
   const int slot = blockIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int q = ONEWAVE ? 0 : wv; q < (ONEWAVE ? NIN : wv + 1); q++) {
@@ -582,10 +614,16 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
   __syncthreads();
   if (STAGE == 5) {
     if (threadIdx.x < UWSPR_NJIG + 3)
-      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x, njig);
+      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x, njig, &s_wsrc);
   } else if (threadIdx.x == 0) {
-    sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0);
+    sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, 0, njig, &s_wsrc);
   }
+  __syncthreads();
+  // the stage winner's tone magnitudes become the slot's kept row (cf. k6_sched's keep_winner)
+  const int ws = s_wsrc;
+  if (pwin && ws >= 0)
+    for (int e = threadIdx.x; e < UWSPR_NSYM; e += blockDim.x)
+      pwin[(size_t)slot * UWSPR_NSYM + e] = p[((size_t)slot * NIN + ws) * UWSPR_NSYM + e];
 }
 
 // out[slot]: state + per-try sync / rms / shift / symbols (cc:465-475)
@@ -674,7 +712,7 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots, int njig) {
   const int reuse = c->reuse_centre ? 1 : 0;
   auto go = [&](auto kern, int threads) {
     hipLaunchKernelGGL(kern, g, dim3(threads), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps,
-                       c->d_cent, c->d_cent_frame, nslots, reuse, njig);
+                       c->d_cent, c->d_cent_frame, nslots, reuse, njig, (float4 *)c->d_pwin);
   };
   const bool one = c->k5_onewave;
   if (c->fast_now) {
@@ -710,6 +748,21 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots, int njig) {
       default: go(k5_fold_step<5, false, false>, 320); break;
     }
   }
+}
+
+// lazy tries: try 0's magnitudes are what uwspr_demod_resume starts from -- already kept when try 0 was the
+// known hypothesis, copied here when it was correlated (no stage-4 winner to repeat)
+__global__ void k_keep_try0(const dev_hyp *__restrict__ h5, const float4 *__restrict__ p, float4 *__restrict__ pwin,
+                            int njig, int nslots) {
+  const int slot = blockIdx.x;
+  if (slot >= nslots || h5[(size_t)slot * njig].frame < 0) return;   // known (<= -2) or dead (-1): nothing to copy
+  for (int e = threadIdx.x; e < UWSPR_NSYM; e += blockDim.x)
+    pwin[(size_t)slot * UWSPR_NSYM + e] = p[(size_t)slot * njig * UWSPR_NSYM + e];
+}
+
+void launch_keep_try0(uwspr_ctx *c, int nslots, int njig) {
+  dev_hyp *h5 = c->d_hyps + (size_t)nslots * UWSPR_NJIG;
+  hipLaunchKernelGGL(k_keep_try0, dim3(nslots), dim3(192), 0, c->stream, h5, c->d_p, (float4 *)c->d_pwin, njig, nslots);
 }
 
 void launch_sched_finish(uwspr_ctx *c, int nslots, int njig) {

@@ -757,7 +757,8 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
   dev_hyp *half[2] = {c->d_hyps, c->d_hyps + nslots * UWSPR_NJIG};
   launch_sched_init(c, dcands, dnpk, cand_stride, B, per_frame);
   const bool lazy = njig < UWSPR_NJIG;   // only tries idt < njig of stage 5, packed njig per slot
-  if (lazy && (rc = ensure(c, &c->d_pwin, &c->cap_pwin, nslots * UWSPR_NSYM * 4))) return rc;
+  // the stage winner's magnitudes, carried from stage to stage (try 0 of stage 5 repeats the stage-4 winner)
+  if ((rc = ensure(c, &c->d_pwin, &c->cap_pwin, nslots * UWSPR_NSYM * 4))) return rc;
   for (int s = 0; s < 6; s++) {
     c->fast_now = c->fast_search && s < 5;   // S5 (the soft symbols) is always the reference's arithmetic
     const int H = (int)(nslots * (s == 5 ? njig : hpc[s]));
@@ -787,11 +788,9 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
       launch_fold_step(c, s + 1, (int)nslots, njig);   // fold of stage s + transition to stage s+1
       c->fast_now = false;
     } else {
-      launch_fold(c, h, c->d_p, H, c->d_sync, c->d_sym);
+      launch_fold(c, h, c->d_p, H, c->d_sync, c->d_sym, (const float4 *)c->d_pwin, njig);
       launch_sched_finish(c, (int)nslots, njig);
-      if (lazy)   // try 0's tone magnitudes = the winner's: what uwspr_demod_resume starts from
-        HIPCHK(c, hipMemcpy2DAsync(c->d_pwin, UWSPR_NSYM * 16, c->d_p, (size_t)njig * UWSPR_NSYM * 16,
-                                   UWSPR_NSYM * 16, nslots, hipMemcpyDeviceToDevice, c->stream));
+      if (lazy) launch_keep_try0(c, (int)nslots, njig);   // what uwspr_demod_resume starts from
     }
   }
   HIPCHK(c, hipGetLastError());

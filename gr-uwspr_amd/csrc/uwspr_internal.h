@@ -166,7 +166,7 @@ struct uwspr_ctx {
   // passed at cc:413-465), capped at fl where the reference would read past its arrays.
   int fstride, np;
   int ntries;                         // mode-2 tries per candidate a schedule call produces (uwspr_set_tries)
-  size_t cap_pwin; float *d_pwin;     // [nslots][162][4] winner magnitudes kept for uwspr_demod_resume (ntries < 17)
+  size_t cap_pwin; float *d_pwin;     // [nslots][162][4] magnitudes of the stage winner (f1, shift1, drift1): try 0 of stage 5, and what uwspr_demod_resume starts from
   size_t cap_need; uint8_t *d_need;   // staging of the resume mask
   int last_slots, last_sched_B, last_sched_per_frame;
   bool last_sched_lazy; uwspr_demod_out *last_sched_out;   // what uwspr_demod_resume may continue (run_schedule)
@@ -206,7 +206,8 @@ bool launch_tonecorr_stage_grid(uwspr_ctx *c, const float *frames, int nframes, 
                                 const uwspr_candidate *centres, const int32_t *cframe, int nf,
                                 const float *df, int ndrift, const float *ddrift, float4 *p);
 void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, float *sync,
-                 uint8_t *symbols);
+                 uint8_t *symbols, const float4 *pwin = nullptr, int per_slot = 1);
+void launch_keep_try0(uwspr_ctx *c, int nslots, int njig);
 // schedule stages; see k5_schedule.hip
 void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t *npk,
                        int cand_stride, int B, int per_frame);
