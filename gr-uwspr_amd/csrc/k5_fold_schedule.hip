@@ -33,19 +33,28 @@ __device__ __forceinline__ void k5_wave_fence() {
 // (row stride 36 dwords: conflict-free ds_read_b128); the soft-symbol bytes go
 // back the same way (LDS image, then 10 368 contiguous bytes per wavefront).
 constexpr int K5L_CH = 9;                       // symbols per staged chunk: 162 = 18 x 9
+// pwin / per_slot (stage 5 of the schedule, else null): a hypothesis marked known (frame <= -2: try 0 repeating
+// the stage-4 winner) is live and takes its 162 rows from pwin[h / per_slot] (the magnitudes carried for it)
 __global__ __launch_bounds__(64) void k5_fold(const dev_hyp *__restrict__ hyps,
                                               const float4 *__restrict__ p, int H,
                                               float symfac, float *__restrict__ sync,
-                                              uint8_t *__restrict__ symbols) {
+                                              uint8_t *__restrict__ symbols,
+                                              const float4 *__restrict__ pwin, int per_slot) {
   __shared__ __align__(16) float4 tile[64 * K5L_CH];          // [hyp][9]
   __shared__ __align__(16) uint8_t bytes[64 * UWSPR_NSYM];    // [hyp][162]
+  __shared__ int rowoff[64];                                  // float4 index of each hypothesis' row 0, or -1: in pwin
+  __shared__ int rowslot[64];
   const int lane = threadIdx.x;
   const int h0 = blockIdx.x * 64;
   const int nh = min(64, H - h0);
   const int h = h0 + min(lane, nh - 1);
-  const bool live = lane < nh && hyps[h].frame >= 0;
+  const int fr = hyps[h].frame;
+  const bool known = pwin != nullptr && fr <= -2;
+  const bool live = lane < nh && (fr >= 0 || known);
   const bool soft = symbols != nullptr;
   const float4 *base = p + (size_t)h0 * UWSPR_NSYM;
+  rowoff[lane] = known ? -1 : min(lane, nh - 1) * UWSPR_NSYM;
+  rowslot[lane] = known ? h / per_slot : 0;
 
   auto stage = [&](int c) {   // chunk c of the 64 rows -> tile
     k5_wave_fence();
@@ -53,7 +62,9 @@ __global__ __launch_bounds__(64) void k5_fold(const dev_hyp *__restrict__ hyps,
     for (int j = 0; j < K5L_CH; j++) {
       const int idx = lane + 64 * j;                 // 0..575: hyp = idx / 9, sym = idx % 9
       const int hy = idx / K5L_CH, sy = idx - hy * K5L_CH;
-      tile[idx] = base[(size_t)min(hy, nh - 1) * UWSPR_NSYM + c * K5L_CH + sy];
+      const int ro = rowoff[hy];
+      tile[idx] = ro >= 0 ? base[(size_t)ro + c * K5L_CH + sy]
+                          : pwin[(size_t)rowslot[hy] * UWSPR_NSYM + c * K5L_CH + sy];
     }
     k5_wave_fence();
   };
@@ -306,10 +317,11 @@ void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, floa
                  uint8_t *symbols, const float4 *pwin, int per_slot) {
   if (H <= 0) return;
   prof_scope ps(c, UWSPR_K_FOLD, H);
-  // lanes form from 32768 hypotheses up (UWSPR_K5_LANES=0/1 forces one or the other); the schedule's
-  // stage 5 (carried magnitudes for the known try) always takes the wave form
+  // lanes form from 32768 hypotheses up (UWSPR_K5_LANES=0/1 forces one or the other) and, by default, for the
+  // schedule's stage 5 (UWSPR_K5_S5_LANES=0: wave form): one LANE per try walks the serial sums -- 68 wavefronts
+  // instead of 4352 for 256 slots, a twentieth of the instructions (the chip is VALU-issue bound under overlap)
   static const int forced = getenv("UWSPR_K5_LANES") ? atoi(getenv("UWSPR_K5_LANES")) : -1;
-  const bool lanes_form = !pwin && (forced >= 0 ? forced != 0 : H >= 32768);
+  const bool lanes_form = forced >= 0 ? forced != 0 : (H >= 32768 || (pwin != nullptr && c->k5_s5_lanes));
   if (per_slot < 1) per_slot = 1;
   if (!lanes_form) {
     dim3 g((H + K5W_WAVES - 1) / K5W_WAVES), b(64 * K5W_WAVES);
@@ -322,7 +334,7 @@ void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, floa
     }
   } else {
     hipLaunchKernelGGL(k5_fold, dim3((H + 63) / 64), dim3(64), 0, c->stream, hyps, p, H, 50.0f,
-                       sync, symbols);
+                       sync, symbols, pwin, per_slot);
   }
 }
 
