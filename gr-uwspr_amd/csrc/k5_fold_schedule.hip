@@ -317,9 +317,10 @@ void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, floa
                  uint8_t *symbols, const float4 *pwin, int per_slot) {
   if (H <= 0) return;
   prof_scope ps(c, UWSPR_K_FOLD, H);
-  // lanes form from 32768 hypotheses up (UWSPR_K5_LANES=0/1 forces one or the other) and, by default, for the
-  // schedule's stage 5 (UWSPR_K5_S5_LANES=0: wave form): one LANE per try walks the serial sums -- 68 wavefronts
-  // instead of 4352 for 256 slots, a twentieth of the instructions (the chip is VALU-issue bound under overlap)
+  // lanes form from 32768 hypotheses up (UWSPR_K5_LANES=0/1 forces one or the other).  The schedule's stage 5
+  // (4352 tries for 256 slots) stays on the wave form: through the lanes form (UWSPR_K5_S5_LANES=1) it is 68
+  // wavefronts and a twentieth of the instructions, but each walks 162 symbols serially -- 169 us instead of
+  // 64 on the lane's critical path, -4 % frames/s under three streams (round-3 A/B)
   static const int forced = getenv("UWSPR_K5_LANES") ? atoi(getenv("UWSPR_K5_LANES")) : -1;
   const bool lanes_form = forced >= 0 ? forced != 0 : (H >= 32768 || (pwin != nullptr && c->k5_s5_lanes));
   if (per_slot < 1) per_slot = 1;

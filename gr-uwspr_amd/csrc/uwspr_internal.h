@@ -150,7 +150,7 @@ struct uwspr_ctx {
   // the reference's arithmetic; S5 and every other entry point stay exact).  fast_now: set around those launches.
   bool fast_search, fast_now;
   bool k4f_onegen;       // k4_fstage: wavefront 0 generates all four tones' phasor tables (UWSPR_K4F_ONEGEN=0: each its own)
-  bool k5_s5_lanes;      // the schedule's stage-5 fold through the lanes form (UWSPR_K5_S5_LANES=0: wave form)
+  bool k5_s5_lanes;      // UWSPR_K5_S5_LANES=1: the schedule's stage-5 fold through the lanes form (measured slower: 68 long wavefronts)
   bool k5_onewave;       // UWSPR_K5_ONEWAVE=1: one wavefront per slot folds its hypotheses in turn (5 KB LDS, not 26)
   // fused schedule (k6_sched: one workgroup per candidate runs S0..S5; UWSPR_SCHED_FUSED=0: staged launches)
   bool use_fused; bool sched_nopad; int sched_grid;
