@@ -204,7 +204,7 @@ def main():
     # the same reason; they idle until their legs run
     host_legs = rank == 0 and world == 1 and not args.no_host_legs and args.total_frames <= 0
     pipes_e2e = {f: G.Pipe(batch_frames=B, max_per_frame=1, lanes=3, sched=f) for f in ("fused", "staged")} if host_legs else {}
-    pipe_st = G.Pipe(hop=3375, batch_frames=B, max_per_frame=1, lanes=3, sched="staged") if host_legs else None
+    pipe_st = G.Pipe(hop=3375, batch_frames=B, max_per_frame=1, lanes=3) if host_legs else None
 
     def make_lanes(ns, fused):
         os.environ["UWSPR_SCHED_FUSED"] = "1" if fused else "0"

@@ -16,6 +16,7 @@
 // lib/sync_and_demodulate_impl.cc:315-534; the lazy tries are cc:457-490's early exit).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -321,8 +322,12 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
     const int rc = uwspr_ctx_create(p, device, &L.ctx);
     if (rc) return pfail(q, rc, "uwspr_ctx_create: %s", L.ctx ? uwspr_last_error(L.ctx) : uwspr_status_string(rc));
     L.stream = L.ctx->own_stream;
+    // schedule form: with three or more batches in flight the staged launches leave room for the other
+    // lanes' kernels and win (861 k against 773 k decoded frames/s at 3 lanes); alone or in pairs the fused
+    // kernel does (tools/pipe_lanes_probe.py).  UWSPR_SCHED_FUSED in the environment still decides when set.
     if (q->o.sched_form == 1) L.ctx->use_fused = true;
-    if (q->o.sched_form == 2) L.ctx->use_fused = false;
+    else if (q->o.sched_form == 2) L.ctx->use_fused = false;
+    else if (!getenv("UWSPR_SCHED_FUSED")) L.ctx->use_fused = q->o.lanes < 3;
     PHIP(q, hipMalloc((void **)&L.d_cands, (size_t)Bm * p->maxfreqs * sizeof(uwspr_candidate)));
     PHIP(q, hipMalloc((void **)&L.d_npk, (size_t)Bm * sizeof(int32_t)));
     PHIP(q, hipMalloc((void **)&L.d_out, (size_t)Bm * per * sizeof(uwspr_demod_out)));

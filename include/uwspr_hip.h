@@ -349,7 +349,7 @@ typedef struct uwspr_pipe_opts {
   int32_t lanes;          /* batches in flight, each with its own context and HIP stream (0: 3) */
   int32_t host_threads;   /* Fano threads (0: uwspr_host_threads() - 2, leaving the producer and the HIP runtime a core each) */
   int32_t eager;          /* 1: all 17 tries in the first pass, no resume (A/B against the lazy flow) */
-  int32_t sched_form;     /* 0: as the contexts default (UWSPR_SCHED_FUSED), 1: fused kernel, 2: staged launches */
+  int32_t sched_form;     /* 0: staged launches from 3 lanes up, the fused kernel below (UWSPR_SCHED_FUSED overrides), 1: fused, 2: staged */
   int32_t _reserved;
 } uwspr_pipe_opts;
 /* one refined candidate (j < min(npk, max_per_frame)) of one frame */
