@@ -376,10 +376,10 @@ def main():
     nlive, nlin, nworth = int(live.sum()), int((live & top_lin).sum()), int(worth.sum())
     # hypotheses the reference resolves per candidate: S0 5, S1 5, S2 2 (linear), S3 5, S4 5, S5 17
     fine_hyps = 10 * nlive + 2 * nlin + 27 * nworth
-    # correlations the kernels run: the stage winner repeated by S1/S3/S4 is carried, S0's last lag is
-    # its first one symbol later (both forms); the fused form also carries try 0 of S5
+    # correlations the kernels run: the stage winner repeated by S1/S3/S4 and by try 0 of S5 is carried
+    # (both forms since round 3), S0's last lag is its first one symbol later
     reuse_on = os.environ.get("UWSPR_K4_REUSE", "1") != "0"
-    fine_corr = fine_hyps - ((nlive + 2 * nworth) if reuse_on else 0) - nlive - (nworth if (fused and reuse_on) else 0)
+    fine_corr = fine_hyps - ((nlive + 3 * nworth) if reuse_on else 0) - nlive
     # binary32 operations those correlations need: 8 per sample, tone and hypothesis; the per-symbol
     # phasor recurrences (6) only where the algorithm cannot share them (the two drift tries of S2)
     ops_step = float(fine_corr) * OPS_MAC + 2.0 * nlin * OPS_PHASOR
