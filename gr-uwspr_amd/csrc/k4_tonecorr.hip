@@ -476,7 +476,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
 }
 
 void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
-                            int NL, int64_t nhyps, float4 *p) {
+                            int NL, int64_t nhyps, float4 *p, int gps) {
   if (G <= 0) return;
   prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
   const long long total = (long long)G * UWSPR_NSYM;
@@ -502,10 +502,15 @@ void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_
 // slot (c + q) mod M, column r with (q, r) = divmod(k + STEP l, 16) known at
 // compile time; the M slot addresses rotate once per chunk.  Arithmetic per
 // accumulator is exactly k4_group's (cc:193-195, 206-207).
+// Phasor tables (k5_fold_schedule.hip: ptab_build; dev_grp::nvalid bits 16..23 = 1 + table of the slot, 0 = none):
+// when every live group of a wavefront has one, the lanes do not run the recurrence (six instruction slots per
+// sample step) but read c[k], s[k] from a 16-step slice the wavefront fetches per chunk into LDS.
+constexpr int K4_PT_STRIDE = 18;   // float2 per (group, tone) row of the slice: 16 steps + pad (16-B rows on distinct banks)
+
 template <int NL, int STEP, bool FAST = false>
 __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
     const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_grp *__restrict__ grps,
-    int G, float *__restrict__ p_out) {
+    int G, float *__restrict__ p_out, const float2 *__restrict__ ptab, int gps) {
   constexpr int PPW = 16;
   constexpr int W = (NL - 1) * STEP;       // extra samples beyond the first lag's window
   constexpr int Q = (15 + W) / 16;         // furthest slot a chunk reaches ahead
@@ -513,10 +518,12 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   constexpr int NSLOT = 16 + Q;            // slots a pair needs in all
   constexpr int RS = 32 * M + 4;           // dwords per pair row: 16-byte aligned, rows of a lane group on distinct banks
   __shared__ __align__(16) float lds_all[K4G_WAVES][PPW * RS];
+  __shared__ __align__(16) float2 ptl_all[K4G_WAVES][8 * K4_PT_STRIDE];
 
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float *lds = lds_all[wv];
+  float2 *ptl = ptl_all[wv];
 
   const long long total = (long long)G * UWSPR_NSYM;
   const unsigned lblock = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -532,6 +539,17 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   const bool okB = (gA + 1 < G) && Bg.frame >= 0 && Bg.frame < nframes;
   const int frA = okA ? A.frame : 0, frB = okB ? Bg.frame : 0;
   const int nvA = okA ? (A.nvalid & 0xff) : 0, nvB = okB ? (Bg.nvalid & 0xff) : 0;
+  // phasor tables: the table walk only when every live group of the wavefront has one (wave-uniform)
+  const int selA = okA ? (A.nvalid >> 16) & 0xff : 0, selB = okB ? (Bg.nvalid >> 16) & 0xff : 0;
+  const bool liveB = sb < PPW && okB;
+  const bool use_tab = ptab != nullptr && (okA || liveB) && (!okA || selA != 0) && (!liveB || selB != 0);
+  const float2 *tabA = ptab, *tabB = ptab;
+  if (use_tab) {
+    if (selA) tabA = ptab + ((size_t)(gA / gps) * kPtabPerSlot + (selA - 1)) * kPtabFloat2;
+    if (selB) tabB = ptab + ((size_t)((gA + 1) / gps) * kPtabPerSlot + (selB - 1)) * kPtabFloat2;
+    if (!selA) tabA = tabB;     // a dead group's lanes read some valid table (their results are discarded)
+    if (!selB) tabB = tabA;
+  }
   // nvalid bit 8: lag slot 2 repeats the previous stage's winner, its metric is known and nobody
   // reads its p[] -- skipped when that holds for every live group of the wave (NL == 5 only)
   const bool knownA = !okA || (A.nvalid & 0x100) != 0, knownB = !okB || (Bg.nvalid & 0x100) != 0;
@@ -549,8 +567,8 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   const bool interior = __all((own_nb > 0) && (own_nb + 255 + 16 * Q < np)  /* the loader fetches whole slots */);
 
   // ---- this lane's tone phasor step (binary64 angle, cc:173-189) ------------
-  float cd, sd;
-  {
+  float cd = 1.0f, sd = 0.0f;
+  if (!use_tab) {   // (with tables the steps are in them)
     const dev_grp &gy = mineA ? A : Bg;
     float fp;
     if (gy.m_type == UWSPR_LINEAR) {
@@ -628,13 +646,34 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
 #pragma unroll
   for (int l = 0; l < NL; l++) { inp[l] = 0.0f; quad[l] = 0.0f; }
 
+  // phasor-table slice of a chunk: 2 groups x 4 tones x 16 steps, two 8-byte loads per lane
+  float2 tstage[2];
+  auto load_tab = [&](int c) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int e = lane + 64 * j, tn = (e >> 4) & 3, st = e & 15;
+      tstage[j] = ((e >> 6) ? tabB : tabA)[tn * 256 + 16 * c + st];
+    }
+  };
+  auto store_tab = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int e = lane + 64 * j;
+      ptl[(e >> 4) * K4_PT_STRIDE + (e & 15)] = tstage[j];
+    }
+  };
+  const int trow = ((mineA ? 0 : 4) + tone) * K4_PT_STRIDE;   // this lane's row of the slice
+  if (use_tab) { load_tab(0); store_tab(); }
+
   int wpos = 0;  // ring position that slot c + Q + 1 will overwrite (= position of slot c)
-  auto walk = [&](auto skip_tag) {
+  auto walk = [&](auto skip_tag, auto tab_tag) {
     constexpr bool SKIP = decltype(skip_tag)::value;   // leave lag slot 2 out
+    constexpr bool TAB = decltype(tab_tag)::value;     // phasors from the table slice, no recurrence
     for (int ch = 0; ch < 16; ch++) {
       // in flight during the chunk's arithmetic (the last chunk re-fetches the last slot: no
       // branch here or after the arithmetic, or the compiler sinks the arithmetic past it)
       load_slot(min(ch + Q + 1, NSLOT - 1));
+      if (TAB) load_tab(min(ch + 1, 15));
       wave_lds_fence();                      // the slots written so far are visible
       // Two samples per read: STEP is even, so sample k + STEP l of an even step k and its
       // successor sit in one 16-byte-aligned LDS word pair -- one ds_read_b128 per lag and two
@@ -661,15 +700,18 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
         }
         // (pinning these reads ahead with sched_barrier -- 86 VGPRs instead of ~145 -- was 7 % slower
         // for S3 and 1 % slower for S5 under three streams: left to the scheduler)
+        float4 ph = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (TAB) ph = *reinterpret_cast<const float4 *>(&ptl[trow + k]);   // (c, s) of steps k and k + 1
 #pragma unroll
         for (int half = 0; half < 2; half++) {
+          const float pc = TAB ? (half ? ph.z : ph.x) : c, psn = TAB ? (half ? ph.w : ph.y) : s;
 #pragma unroll
           for (int l = 0; l < NL; l++) {
             if (SKIP && l == 2) continue;
             const float xx = half ? vc[l].z : vc[l].x, xy = half ? vc[l].w : vc[l].y;
-            k4_mac<FAST>(inp[l], quad[l], xx, xy, c, s);   // cc:206-207
+            k4_mac<FAST>(inp[l], quad[l], xx, xy, pc, psn);   // cc:206-207
           }
-          k4_rot<FAST>(c, s, cd, sd);                // cc:193-195
+          if (!TAB) k4_rot<FAST>(c, s, cd, sd);      // cc:193-195
         }
 #pragma unroll
         for (int l = 0; l < NL; l++) vc[l] = vn[l];
@@ -677,6 +719,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
       // slot ch is finished with: its position takes slot ch + Q + 1, and the addresses rotate
       wave_lds_fence();
       store_slot(wpos);
+      if (TAB) store_tab();
       wpos = (wpos + 1 == M) ? 0 : wpos + 1;
       const int first = sa[0];
 #pragma unroll
@@ -684,7 +727,8 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
       sa[M - 1] = first;
     }
   };
-  if (skip_mid) walk(std::true_type{}); else walk(std::false_type{});
+  if (use_tab) { if (skip_mid) walk(std::true_type{}, std::true_type{}); else walk(std::false_type{}, std::true_type{}); }
+  else { if (skip_mid) walk(std::true_type{}, std::false_type{}); else walk(std::false_type{}, std::false_type{}); }
 
   if (g0 + pr < total) {
     const int nv = mineA ? nvA : nvB;
@@ -707,11 +751,11 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
 
 // lags of every group must be lag[0] + l*step, l < nvalid (the schedule's S3 / S5 emitters)
 void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
-                          int NL, int step, int64_t nhyps, float4 *p) {
+                          int NL, int step, int64_t nhyps, float4 *p, int gps) {
   if (G <= 0) return;
   const bool r5 = NL == 5 && step == 16, r6 = NL == 6 && step == 8;
   if (!r5 && !r6) {   // no ring instance for this spacing: plain lag groups
-    launch_tonecorr_groups(c, frames, B, grps, G, NL <= 5 ? 5 : NL == 6 ? 6 : 8, nhyps, p);
+    launch_tonecorr_groups(c, frames, B, grps, G, NL <= 5 ? 5 : NL == 6 ? 6 : 8, nhyps, p, gps);
     return;
   }
   prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
@@ -721,9 +765,11 @@ void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_gr
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   dim3 blk(64 * K4G_WAVES);
-  if (r5 && c->fast_now) launch_timed(c, ps, (k4_ring<5, 16, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
-  else if (r5) launch_timed(c, ps, (k4_ring<5, 16>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
-  else launch_timed(c, ps, (k4_ring<6, 8>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
+  const float2 *pt = c->use_ptab ? c->d_ptab : nullptr;
+  if (gps < 1) gps = 1;
+  if (r5 && c->fast_now) launch_timed(c, ps, (k4_ring<5, 16, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, pt, gps);
+  else if (r5) launch_timed(c, ps, (k4_ring<5, 16>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, pt, gps);
+  else launch_timed(c, ps, (k4_ring<6, 8>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, pt, gps);
 }
 
 

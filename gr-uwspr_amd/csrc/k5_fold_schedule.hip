@@ -411,11 +411,60 @@ __device__ inline best3 best_of(const float *sy, const dev_hyp *hy, int n) {
   return b;
 }
 
+// ---- phasor tables of the lag stages (staged form) ------------------------------------------------------
+// When the per-symbol frequency does not depend on the symbol (drift == 0 or the straight-line model with
+// t = 0: the reference's `fplast` cache hits for the same reason, cc:185) the sequence c[k], s[k] of cc:186-199 is
+// the same for all 162 symbols of a (frequency, tone).  The lag kernels (k4_group, k4_ring) otherwise run that
+// recurrence in every lane -- six instruction slots per sample step and wavefront; with the table in HBM/L2 they
+// fetch 16 steps per chunk into LDS and read them from there.  Same values: the table IS the recurrence,
+// computed once (constant kTwoPiDt5 etc. as in k4_tonecorr.hip).
+constexpr double kTwoPiDt5 = 2.0 * 3.14159265358979323846 * (double)(float)(1.0 / 375.0);   // cc:146,188
+
+// lanes 0 .. 4 nq - 1 of the calling wavefront: table (q0 + lane / 4) for tone lane & 3, frequency
+// fc + (q - 2) fstep for q = qfirst + lane / 4
+__device__ __forceinline__ void ptab_build(float2 *__restrict__ tabs, int nq, int qfirst, float fc, float fstep,
+                                           int m_type, float drift, float slmc) {
+  const int lane = threadIdx.x & 63;
+  if (lane >= 4 * nq) return;
+  const int qi = lane >> 2, tone = lane & 3, q = qfirst + qi;
+  const float f0 = fc + (float)(q - 2) * fstep;                                       // cc:164
+  const float fp = (m_type == UWSPR_LINEAR)
+                       ? (float)((double)f0 + ((double)drift / 2.0) * ((double)(float)0 - 81.0) / 81.0)
+                       : f0 + slmc;                                                   // cc:173 / cc:179
+  const float delta = ((float)tone - 1.5f) * 1.46484375f;                             // cc:148
+  double sn, cs;
+  sincos(kTwoPiDt5 * (double)(fp + delta), &sn, &cs);                                 // cc:188-189
+  const float cd = (float)cs, sd = (float)sn;
+  float c = 1.0f, sv = 0.0f;
+  float2 *t = tabs + (size_t)qi * kPtabFloat2 + tone * 256;
+#pragma unroll 8
+  for (int k = 0; k < 256; k++) {
+    t[k] = make_float2(c, sv);
+    const float nc = c * cd - sv * sd;   // cc:193-195
+    const float ns = c * sd + sv * cd;
+    c = nc; sv = ns;
+  }
+}
+
+// table selector of a lag group (dev_grp::nvalid bits 16..23): 0 = none (every lane runs the recurrence),
+// else 1 + table index within the slot.  A table applies only if it was built and the group's frequency is
+// bit for bit the one it was built for.
+__device__ __forceinline__ int ptab_select(const cand_state &st, int set, float f0, float drift, bool on) {
+  if (!on) return 0;
+  if (st.m_type == UWSPR_LINEAR && drift != 0.0f) return 0;
+  if (set == 0) return (st.tabA_ok && __float_as_int(f0) == __float_as_int(st.tabA_f)) ? 1 : 0;
+  if (!st.tabB_ok) return 0;
+  for (int q = 0; q < 5; q++)
+    if (__float_as_int(st.tabB_f + (float)(q - 2) * 0.05f) == __float_as_int(f0)) return 2 + q;
+  return 0;
+}
+
 __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
                              const int32_t *__restrict__ npk, int cand_stride, int B,
                              int per_frame, float cf, cand_state *__restrict__ state,
-                             dev_hyp *__restrict__ hyps, dev_grp *__restrict__ grps) {
-  const int slot = blockIdx.x * 256 + threadIdx.x;
+                             dev_hyp *__restrict__ hyps, dev_grp *__restrict__ grps, float2 *__restrict__ ptab) {
+  // one wavefront per slot: every lane derives the same state (lane 0 writes it), lanes 0..3 build table set A
+  const int slot = blockIdx.x;
   if (slot >= B * per_frame) return;
   const int b = slot / per_frame, j = slot - b * per_frame;
   cand_state st;
@@ -437,6 +486,11 @@ __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
     st.shift1 = 0; st.sync1 = 0.0f;
   }
   st.worth = 0; st.driftp = 0.0f; st.driftm = 0.0f; st.csync = 0.0f; st.cknown = 0;
+  // table set A: the candidate frequency (S0's lag sweep), when the frequency does not depend on the symbol
+  st.tabA_f = st.f1; st.tabB_f = 0.0f; st.tabB_ok = 0;
+  st.tabA_ok = (ptab != nullptr && on && (st.m_type != UWSPR_LINEAR || st.drift1 == 0.0f)) ? 1 : 0;
+  if (st.tabA_ok) ptab_build(ptab + (size_t)slot * kPtabPerSlot * kPtabFloat2, 1, 2, st.f1, 0.25f, st.m_type, st.drift1, st.slmc);
+  if (threadIdx.x != 0) return;
   state[slot] = st;
   // S0 (cc:409-415): mode 0, lag = shift1-128 .. shift1+128 step 64, f0 = f1 + 0*0.0f
   dev_hyp *h = hyps + (size_t)slot * 5;
@@ -447,6 +501,7 @@ __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
     emit(&h[q], st, on, lags[q], f0, st.drift1);
   }
   emit_group(&grps[slot], st, on, f0, st.drift1, slot * 5, lags, 5);
+  grps[slot].nvalid |= ptab_select(st, 0, f0, st.drift1, on) << 16;
 }
 
 template <int STAGE>
@@ -457,7 +512,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
                                                 dev_grp *__restrict__ grps,
                                                 uwspr_candidate *__restrict__ cent,
                                                 int32_t *__restrict__ cframe, bool reuse, int team = 0,
-                                                int njig = UWSPR_NJIG, int *wsrc = nullptr) {
+                                                int njig = UWSPR_NJIG, int *wsrc = nullptr, bool tabs = false) {
   // *wsrc (written by team 0): the input hypothesis whose tone magnitudes are now those of the state's
   // (f1, shift1, drift1) -- the stage winner -- or -1: the winner is the hypothesis that was marked known
   // (its magnitudes are the ones already kept) or nobody won.  The workgroup copies them to the slot's kept
@@ -520,6 +575,10 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     }
     emit_group(&grps[slot], st, st.worth != 0, f0, st.drift1, slot * 5, lags, 5);
     if (st.cknown) grps[slot].nvalid |= 0x100;   // lag slot 2 is known: K4 skips it
+    // table set B is built around this f1 by the workgroup right after this (k5_fold_step<3>)
+    st.tabB_f = st.f1;
+    st.tabB_ok = (tabs && st.worth && (st.m_type != UWSPR_LINEAR || st.drift1 == 0.0f)) ? 1 : 0;
+    grps[slot].nvalid |= ptab_select(st, 1, f0, st.drift1, st.worth != 0) << 16;
   } else if (STAGE == 4) {
     // after S3 -> S4 (cc:449-452): f = f1 + ifreq*0.05
     if (st.worth) {
@@ -568,6 +627,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
       emit_group(&grps[slot * 3 + g], st, st.worth != 0 && njig >= UWSPR_NJIG, st.f1, st.drift1,
                  slot * UWSPR_NJIG + idt0, gl, n, hmap);
       if (g == 1 && known0) grps[slot * 3 + g].nvalid |= 0x100;   // its lag slot 2 (m = 8) is try 0: known
+      grps[slot * 3 + g].nvalid |= ptab_select(st, 1, st.f1, st.drift1, st.worth != 0 && njig >= UWSPR_NJIG) << 16;
     }
   }
   if (team == 0) { state[slot] = st; if (wsrc) *wsrc = ws; }
@@ -607,7 +667,7 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
                              const float4 *__restrict__ p, float *__restrict__ sync,
                              dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
                              uwspr_candidate *__restrict__ cent, int32_t *__restrict__ cframe, int nslots,
-                             int reuse, int njig, float4 *__restrict__ pwin) {
+                             int reuse, int njig, float4 *__restrict__ pwin, float2 *__restrict__ ptab) {
   constexpr int NIN = STAGE == 3 ? 2 : 5;
   __shared__ k5_wave_lds L[LDS ? (ONEWAVE ? 1 : NIN) : 1];
   __shared__ float sy[NIN];
@@ -627,11 +687,16 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
   __syncthreads();
   if (STAGE == 5) {
     if (threadIdx.x < UWSPR_NJIG + 3)
-      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x, njig, &s_wsrc);
+      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x, njig, &s_wsrc, ptab != nullptr);
   } else if (threadIdx.x == 0) {
-    sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, 0, njig, &s_wsrc);
+    sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, 0, njig, &s_wsrc, ptab != nullptr);
   }
   __syncthreads();
+  if (STAGE == 3 && ptab && threadIdx.x < 64) {   // table set B around the f1 the fine stages start from
+    const cand_state st = state[slot];
+    if (st.tabB_ok)
+      ptab_build(ptab + ((size_t)slot * kPtabPerSlot + 1) * kPtabFloat2, 5, 0, st.tabB_f, 0.05f, st.m_type, st.drift1, st.slmc);
+  }
   // the stage winner's tone magnitudes become the slot's kept row (cf. k6_sched's keep_winner)
   const int ws = s_wsrc;
   if (pwin && ws >= 0)
@@ -710,8 +775,9 @@ void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t
                        int cand_stride, int B, int per_frame) {
   const int nslots = B * per_frame;
   prof_scope ps(c, UWSPR_K_SCHED, nslots);
-  hipLaunchKernelGGL(k_sched_init, dim3((nslots + 255) / 256), dim3(256), 0, c->stream, cands,
-                     npk, cand_stride, B, per_frame, (float)c->p.cf, c->d_state, c->d_hyps, c->d_grps);
+  hipLaunchKernelGGL(k_sched_init, dim3(nslots), dim3(64), 0, c->stream, cands,
+                     npk, cand_stride, B, per_frame, (float)c->p.cf, c->d_state, c->d_hyps, c->d_grps,
+                     c->use_ptab ? c->d_ptab : nullptr);
 }
 
 // hyps of consecutive stages ping-pong between the two halves of d_hyps;
@@ -725,7 +791,8 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots, int njig) {
   const int reuse = c->reuse_centre ? 1 : 0;
   auto go = [&](auto kern, int threads) {
     hipLaunchKernelGGL(kern, g, dim3(threads), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps,
-                       c->d_cent, c->d_cent_frame, nslots, reuse, njig, (float4 *)c->d_pwin);
+                       c->d_cent, c->d_cent_frame, nslots, reuse, njig, (float4 *)c->d_pwin,
+                       c->use_ptab ? c->d_ptab : nullptr);
   };
   const bool one = c->k5_onewave;
   if (c->fast_now) {

@@ -130,6 +130,8 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->h_pin = nullptr; c->pin_busy[0] = c->pin_busy[1] = false;
   c->d_stream_frames = nullptr; c->cap_stream_frames = 0; c->ring_ev = nullptr;
   c->fstride = p->fl; c->np = p->fl < 45000 ? p->fl : 45000;   // sync_and_demodulate_impl.cc:92
+  c->cap_ptab = 0; c->d_ptab = nullptr;
+  c->use_ptab = !(getenv("UWSPR_K4_PTAB") && atoi(getenv("UWSPR_K4_PTAB")) == 0);
   c->ntries = UWSPR_NJIG; c->cap_pwin = 0; c->d_pwin = nullptr; c->cap_need = 0; c->d_need = nullptr;
   c->last_slots = 0; c->last_sched_B = 0; c->last_sched_per_frame = 0; c->last_sched_lazy = false; c->last_sched_out = nullptr;
   c->cap_tabs = 0; c->d_tabs = nullptr; c->d_counter = nullptr; c->d_sched_stamps = nullptr; c->cap_sched_stamps = 0;
@@ -284,7 +286,7 @@ extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
   void *bufs[] = {c->d_window, c->d_twiddle, c->d_k3_tile, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
                   c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_cent,
-                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter, c->d_sched_stamps, c->d_pwin, c->d_need, c->d_stream_frames, c->d_tmpc, c->d_tmpn};
+                  c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter, c->d_sched_stamps, c->d_pwin, c->d_ptab, c->d_need, c->d_stream_frames, c->d_tmpc, c->d_tmpn};
   for (void *b : bufs) if (b) (void)hipFree(b);
   c->ring.close();
   if (c->ring_ev) (void)hipEventDestroy(c->ring_ev);
@@ -760,6 +762,7 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
   const bool lazy = njig < UWSPR_NJIG;   // only tries idt < njig of stage 5, packed njig per slot
   // the stage winner's magnitudes, carried from stage to stage (try 0 of stage 5 repeats the stage-4 winner)
   if ((rc = ensure(c, &c->d_pwin, &c->cap_pwin, nslots * UWSPR_NSYM * 4))) return rc;
+  if ((rc = ensure(c, &c->d_ptab, &c->cap_ptab, nslots * kPtabPerSlot * kPtabFloat2))) return rc;
   for (int s = 0; s < 6; s++) {
     c->fast_now = c->fast_search && s < 5;   // S5 (the soft symbols) is always the reference's arithmetic
     const int H = (int)(nslots * (s == 5 ? njig : hpc[s]));
@@ -780,10 +783,10 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
     if (done) { /* launched */ }
     else if (lazy && s == 5) launch_tonecorr(c, dframes, B, h, H, c->d_p);   // few, unrelated lags: the plain kernel
     else if (c->use_fstage && (s == 1 || s == 4)) launch_tonecorr_fstage(c, dframes, B, h, (int)nslots, H, c->d_p);
-    else if (use_groups && s == 3 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)nslots, 5, 16, H, c->d_p);
-    else if (use_groups && s == 5 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, 8, H, c->d_p);
-    else if (use_groups && (s == 0 || s == 3)) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)nslots, 5, H, c->d_p);
-    else if (use_groups && s == 5) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, H, c->d_p);
+    else if (use_groups && s == 3 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)nslots, 5, 16, H, c->d_p, 1);
+    else if (use_groups && s == 5 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, 8, H, c->d_p, 3);
+    else if (use_groups && (s == 0 || s == 3)) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)nslots, 5, H, c->d_p, 1);
+    else if (use_groups && s == 5) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, H, c->d_p, 3);
     else launch_tonecorr(c, dframes, B, h, H, c->d_p);
     if (s < 5) {
       launch_fold_step(c, s + 1, (int)nslots, njig);   // fold of stage s + transition to stage s+1

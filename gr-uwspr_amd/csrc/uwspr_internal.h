@@ -78,7 +78,16 @@ struct cand_state {
   // (same f0, lag, drift): its metric is already known and K4 / the fold skip it.
   float csync;         // metric of (f1, shift1, drift1) when cknown
   int32_t cknown;
+  // staged form: phasor tables of the lag stages (k5: ptab_build): the centre frequency each set was built
+  // around and whether it was built (the frequency did not depend on the symbol at that point)
+  float tabA_f, tabB_f;
+  int32_t tabA_ok, tabB_ok;
 };
+// phasor tables of the staged schedule's lag stages, per slot: table 0 = set A (candidate frequency: S0),
+// tables 1..5 = set B (f1 + {-2..2} 0.05 Hz after S2: S3 uses the middle one, S5 the stage-4 winner's);
+// each [4 tones][256 steps] (c, s) -- the sequence of cc:186-199
+constexpr int kPtabPerSlot = 6;
+constexpr int kPtabFloat2 = 4 * 256;   // float2 per table
 
 struct fdr_consts {
   int fl, n, size, m, hpbm, finpb, noiseidx, maxfreqs, maxdrift;
@@ -167,6 +176,8 @@ struct uwspr_ctx {
   // passed at cc:413-465), capped at fl where the reference would read past its arrays.
   int fstride, np;
   int ntries;                         // mode-2 tries per candidate a schedule call produces (uwspr_set_tries)
+  size_t cap_ptab; float2 *d_ptab;    // [nslots][kPtabPerSlot][4][256] phasor tables of the lag stages (staged form)
+  bool use_ptab;                      // UWSPR_K4_PTAB=0: every lane runs its own recurrence (same values)
   size_t cap_pwin; float *d_pwin;     // [nslots][162][4] magnitudes of the stage winner (f1, shift1, drift1): try 0 of stage 5, and what uwspr_demod_resume starts from
   size_t cap_need; uint8_t *d_need;   // staging of the resume mask
   int last_slots, last_sched_B, last_sched_per_frame;
@@ -194,11 +205,11 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
                      float4 *p);
 // lag-group form: G groups, each instantiated for NL in {5, 6, 8} lags
 void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
-                            int NL, int64_t nhyps, float4 *p);
+                            int NL, int64_t nhyps, float4 *p, int groups_per_slot = 1);
 void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int nslots,
                             int64_t nhyps, float4 *p);
 void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
-                          int NL, int step, int64_t nhyps, float4 *p);
+                          int NL, int step, int64_t nhyps, float4 *p, int groups_per_slot = 1);
 // grid form (one centre per frame, shared sample windows); false = does not fit, use the flat path
 bool launch_tonecorr_grid(uwspr_ctx *c, const float *frames, int B, const uwspr_candidate *centres,
                           int nf, const float *df, int ndrift, const float *ddrift, int nlag,
