@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UWSPR_ABI_VERSION 1
+#define UWSPR_ABI_VERSION 2   /* 2: frame stride, in-place stream views, uwspr_pipe_*, uwspr_dist_*, uwspr_host_threads */
 
 typedef enum {
   UWSPR_OK = 0,
