@@ -38,6 +38,7 @@ form = "fused" if "fused" in b["config"].get("sched", "") else "staged"
 b["roofline"]["traffic"] = t[form]["bytes_per_step"]
 b["roofline"]["valu_issue_utilisation_pmc"] = t[form]["valu_issue_utilisation"]
 b["roofline"]["traffic_source"] = t[form]["source"]
+b["roofline"]["traffic_stale"] = None   # the counters are this run's own
 open(sys.argv[1], "w").write(json.dumps(b) + "\n")
 PY
 wc -l ${O}_rocprof_summary.txt
