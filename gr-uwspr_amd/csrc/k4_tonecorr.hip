@@ -965,11 +965,210 @@ __global__ __launch_bounds__(256) void k4_fstage(
   }
 }
 
+// Packed form of the frequency stage: the (slot, symbol) pairs of the whole launch are flattened and a
+// workgroup takes 64 consecutive ones -- all 64 lanes of its four tone wavefronts work (k4_fstage's three
+// parts of 54 symbols leave ten lanes in 64 idle: a sixth of the stage's multiply-add instructions).  A workgroup
+// then spans at most two slots (162 > 64): two sets of hypothesis parameters, two phasor-table sets in LDS
+// (generated by lanes 0..39 of wavefront 0), each lane reading its own slot's.  Arithmetic per accumulator and
+// per phasor is k4_fstage's, i.e. the reference's sequence.  Fallbacks inside: a slot whose frequency depends on
+// the symbol (drifting linear model) puts the whole workgroup on per-lane recurrences; the known middle frequency
+// is left out only when every live slot of the workgroup has it marked.
+template <int NF, int CH, bool FAST = false>
+__global__ __launch_bounds__(256) void k4_fpack(
+    const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_hyp *__restrict__ hyps,
+    int nslots, float *__restrict__ p_out) {
+  constexpr int ROWS = 64;
+  constexpr int ROWDW = 2 * CH + 4;       // dwords per staged row: CH samples x 8 B + 16 B pad (16-byte aligned)
+  constexpr int NCH = 256 / CH;           // chunks per symbol
+  constexpr int SEGS = 256 / CH;          // rows staged per loader round
+  constexpr int NR = ROWS / SEGS;
+  __shared__ __align__(16) float smp[ROWS * ROWDW];
+  __shared__ __align__(16) float4 tab[2][4][CH / 2][NF];   // [slot A/B][tone]: (c, s) of steps 2j and 2j+1 per frequency
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int tone = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long total = (long long)nslots * UWSPR_NSYM;
+  const long long g0 = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * ROWS;
+  if (g0 >= total) return;  // workgroup-uniform
+
+  const int slotA = (int)(g0 / UWSPR_NSYM);
+  const int iA0 = (int)(g0 - (long long)slotA * UWSPR_NSYM);
+  const int sb = min(ROWS, UWSPR_NSYM - iA0);            // rows < sb belong to slot A
+  const bool hasB = sb < ROWS && slotA + 1 < nslots;
+  const int slotB = hasB ? slotA + 1 : slotA;
+  const dev_hyp hA = hyps[(size_t)slotA * NF], hB = hyps[(size_t)slotB * NF];
+  float fA[NF], fB[NF];
+#pragma unroll
+  for (int q = 0; q < NF; q++) { fA[q] = hyps[(size_t)slotA * NF + q].f0; fB[q] = hyps[(size_t)slotB * NF + q].f0; }
+  const bool liveA = hA.frame >= 0 && hA.frame < nframes;
+  const bool liveB = hasB && hB.frame >= 0 && hB.frame < nframes;
+  const bool tabA = (hA.m_type != UWSPR_LINEAR) || (hA.drift == 0.0f);     // fp independent of the symbol
+  const bool tabB = (hB.m_type != UWSPR_LINEAR) || (hB.drift == 0.0f);
+  const bool knownA = hyps[(size_t)slotA * NF + NF / 2].frame <= -2, knownB = hyps[(size_t)slotB * NF + NF / 2].frame <= -2;
+  // workgroup-uniform modes
+  const bool tabled = (!liveA || tabA) && (!liveB || tabB);
+  const bool skip_mid = (liveA || liveB) && (!liveA || knownA) && (!liveB || knownB);
+
+  const int row = lane;
+  const bool mineA = row < sb;
+  const int own_i = mineA ? iA0 + row : row - sb;
+  const int own_slot = mineA ? slotA : slotB;
+  const bool own_live = mineA ? liveA : liveB;
+  const bool valid = (g0 + row < total) && (mineA || hasB);
+  const dev_hyp &ho = mineA ? hA : hB;
+  const float delta = ((float)tone - 1.5f) * 1.46484375f;                    // cc:148
+
+  // ---- loader: round r of a chunk = row SEGS r + tid/CH, sample tid%CH ----
+  const int kk = tid % CH, seg = tid / CH;
+  const float2 *fbA = frames + (long long)(liveA ? hA.frame : 0) * fstride;
+  const float2 *fbB = frames + (long long)(liveB ? hB.frame : 0) * fstride;
+  const int nA0 = hA.lag + 256 * iA0, nB0 = hB.lag;                          // first sample of the first row of each slot
+  const bool interior = liveA && (nA0 > 0) && (nA0 + 256 * sb < np) &&
+                        (sb >= ROWS || (liveB && (nB0 > 0) && (nB0 + 256 * (ROWS - sb) < np)));   // workgroup-uniform
+  float2 stage[NR];
+  int nrow[NR];
+  bool rowB[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const int rw = SEGS * r + seg;
+    rowB[r] = rw >= sb;
+    nrow[r] = (rowB[r] ? nB0 + 256 * (rw - sb) : nA0 + 256 * rw) + kk;
+  }
+  auto load_chunk = [&](int c) {
+    if (interior) {
+#pragma unroll
+      for (int r = 0; r < NR; r++) stage[r] = (rowB[r] ? fbB : fbA)[nrow[r] + CH * c];
+    } else {
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+        const int n = nrow[r] + CH * c;
+        const bool inr = (n > 0) && (n < np);      // cc:205, sample 0 excluded
+        const float2 v = (rowB[r] ? fbB : fbA)[min(max(n, 0), np - 1)];
+        stage[r] = inr ? v : make_float2(0.0f, 0.0f);
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+      *reinterpret_cast<float2 *>(&smp[(SEGS * r + seg) * ROWDW + 2 * kk]) = stage[r];
+  };
+
+  float inp[NF], quad[NF];
+#pragma unroll
+  for (int q = 0; q < NF; q++) { inp[q] = 0.0f; quad[q] = 0.0f; }
+
+  if (tabled) {
+    // the 2 x NF x 4 recurrences (slot, frequency, tone) run on lanes 0 .. 8 NF - 1 of wavefront 0
+    float cq = 1.0f, sq = 0.0f, cdq = 1.0f, sdq = 0.0f;
+    const int gs = lane >= 4 * NF ? 1 : 0, gl = lane - gs * 4 * NF;
+    const int gq = gl % NF, gt = min(gl / NF, 3);
+    const bool gen = (tone == 0) && (lane < 8 * NF) && (gs ? liveB : liveA);
+    if (gen) {
+      float fq = gs ? fB[0] : fA[0];
+#pragma unroll
+      for (int q = 1; q < NF; q++) fq = (gq == q) ? (gs ? fB[q] : fA[q]) : fq;
+      const dev_hyp &hg = gs ? hB : hA;
+      const float fp = (hg.m_type == UWSPR_LINEAR)
+                           ? (float)((double)fq + ((double)hg.drift / 2.0) * ((double)(float)0 - 81.0) / 81.0)
+                           : fq + hg.slmc;                                   // cc:173 / cc:179 (drift == 0)
+      const float gdelta = ((float)gt - 1.5f) * 1.46484375f;                 // cc:148
+      double sn, cs;
+      sincos(kTwoPiDt * (double)(fp + gdelta), &sn, &cs);
+      cdq = (float)cs;
+      sdq = (float)sn;
+    }
+    const float4 *mytab = &tab[mineA ? 0 : 1][tone][0][0];
+    load_chunk(0);
+    auto walk = [&](auto skip_tag) {
+      constexpr bool SKIP = decltype(skip_tag)::value;
+      for (int ch = 0; ch < NCH; ch++) {
+        __syncthreads();              // the previous chunk has been read by everyone
+        store_chunk();
+        if (gen) {
+#pragma unroll
+          for (int k = 0; k < CH; k++) {
+            reinterpret_cast<float2 *>(&tab[gs][gt][k >> 1][gq])[k & 1] = make_float2(cq, sq);
+            k4_rot<FAST>(cq, sq, cdq, sdq);         // cc:193-195
+          }
+        }
+        __syncthreads();
+        load_chunk(min(ch + 1, NCH - 1));  // in flight during the arithmetic (no branch around it)
+#pragma unroll
+        for (int k = 0; k < CH; k += 2) {
+          // two samples and two phasor steps per LDS read (ds_read_b128)
+          const float4 x = *reinterpret_cast<const float4 *>(&smp[row * ROWDW + 2 * k]);
+#pragma unroll
+          for (int q = 0; q < NF; q++) {
+            if (SKIP && q == NF / 2) continue;
+            const float4 ph = mytab[(k >> 1) * NF + q];   // two addresses per wavefront (slot A / slot B rows)
+            k4_mac<FAST>(inp[q], quad[q], x.x, x.y, ph.x, ph.y);      // cc:206-207, step k
+            k4_mac<FAST>(inp[q], quad[q], x.z, x.w, ph.z, ph.w);      // step k + 1
+          }
+        }
+      }
+    };
+    if (skip_mid) walk(std::true_type{}); else walk(std::false_type{});
+  } else {
+    float c[NF], s[NF], cd[NF], sd[NF];
+#pragma unroll
+    for (int q = 0; q < NF; q++) {
+      const float f0 = mineA ? fA[q] : fB[q];
+      const float fp = (ho.m_type == UWSPR_LINEAR)
+                           ? (float)((double)f0 + ((double)ho.drift / 2.0) * ((double)(float)own_i - 81.0) / 81.0)  // cc:173
+                           : f0 + ho.slmc;                                                                         // cc:179
+      double sn, cs;
+      sincos(kTwoPiDt * (double)(fp + delta), &sn, &cs);
+      cd[q] = (float)cs; sd[q] = (float)sn; c[q] = 1.0f; s[q] = 0.0f;
+    }
+    load_chunk(0);
+    for (int ch = 0; ch < NCH; ch++) {
+      __syncthreads();
+      store_chunk();
+      __syncthreads();
+      load_chunk(min(ch + 1, NCH - 1));
+#pragma unroll
+      for (int k = 0; k < CH; k += 2) {
+        const float4 x4 = *reinterpret_cast<const float4 *>(&smp[row * ROWDW + 2 * k]);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+          const float xx = half ? x4.z : x4.x, xy = half ? x4.w : x4.y;
+#pragma unroll
+          for (int q = 0; q < NF; q++) {
+            k4_mac<FAST>(inp[q], quad[q], xx, xy, c[q], s[q]);        // cc:206-207
+            k4_rot<FAST>(c[q], s[q], cd[q], sd[q]);                  // cc:193-195
+          }
+        }
+      }
+    }
+  }
+
+  if (valid) {
+#pragma unroll
+    for (int q = 0; q < NF; q++) {
+      float *o = &p_out[(((long long)own_slot * NF + q) * UWSPR_NSYM + own_i) * 4 + tone];
+      if (!own_live) *o = 0.0f;                                   // skipped slot: its hypotheses read as zeros
+      else if (!(skip_mid && q == NF / 2)) *o = ieee_sqrtf(inp[q] * inp[q] + quad[q] * quad[q]);   // cc:211
+    }
+  }
+}
+
 // hyps: nslots x 5 records; the 5 of a slot must share frame, lag, drift and model (S1 / S4)
 void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int nslots,
                             int64_t nhyps, float4 *p) {
   if (nslots <= 0) return;
   prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
+  if (c->k4_fpack) {
+    const unsigned wgs = (unsigned)(((long long)nslots * UWSPR_NSYM + 63) / 64);
+    if (c->fast_now)
+      launch_timed(c, ps, (k4_fpack<5, K4F_CHUNK, true>), dim3(wgs), dim3(256), 0,
+                   (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p);
+    else
+      launch_timed(c, ps, (k4_fpack<5, K4F_CHUNK>), dim3(wgs), dim3(256), 0,
+                   (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p);
+    return;
+  }
   if (c->fast_now)
     launch_timed(c, ps, (k4_fstage<5, K4F_CHUNK, true>), dim3(3u * (unsigned)nslots), dim3(256), 0,
                  (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p, c->k4f_onegen ? 1 : 0);

@@ -112,6 +112,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->use_fstage = !(getenv("UWSPR_K4_FSTAGE") && atoi(getenv("UWSPR_K4_FSTAGE")) == 0);
   c->reuse_centre = !(getenv("UWSPR_K4_REUSE") && atoi(getenv("UWSPR_K4_REUSE")) == 0);
   c->use_k5_lds = !(getenv("UWSPR_K5_LDS") && atoi(getenv("UWSPR_K5_LDS")) == 0);
+  c->k4_fpack = !(getenv("UWSPR_K4_FPACK") && atoi(getenv("UWSPR_K4_FPACK")) == 0);
   c->k4f_onegen = !(getenv("UWSPR_K4F_ONEGEN") && atoi(getenv("UWSPR_K4F_ONEGEN")) == 0);
   c->k5_s5_lanes = getenv("UWSPR_K5_S5_LANES") && atoi(getenv("UWSPR_K5_S5_LANES")) != 0;
   c->k5_onewave = getenv("UWSPR_K5_ONEWAVE") && atoi(getenv("UWSPR_K5_ONEWAVE")) != 0;

@@ -158,6 +158,7 @@ struct uwspr_ctx {
   // UWSPR_FAST_SEARCH=1: stages S0..S4 of the schedule with fused multiply-adds and shuffle-tree sums (not
   // the reference's arithmetic; S5 and every other entry point stay exact).  fast_now: set around those launches.
   bool fast_search, fast_now;
+  bool k4_fpack;         // S1/S4 through the packed form (64 consecutive (slot, symbol) pairs per workgroup); UWSPR_K4_FPACK=0: k4_fstage
   bool k4f_onegen;       // k4_fstage: wavefront 0 generates all four tones' phasor tables (UWSPR_K4F_ONEGEN=0: each its own)
   bool k5_s5_lanes;      // UWSPR_K5_S5_LANES=1: the schedule's stage-5 fold through the lanes form (measured slower: 68 long wavefronts)
   bool k5_onewave;       // UWSPR_K5_ONEWAVE=1: one wavefront per slot folds its hypotheses in turn (5 KB LDS, not 26)
