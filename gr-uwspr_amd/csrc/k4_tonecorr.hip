@@ -273,10 +273,11 @@ __device__ unsigned long long g_k4_stamps[K4_STAMP_WAVES * 4];
 #define K4_STAMP(slot) do { } while (0)
 #endif
 
+// skip_tabled: groups whose phasor table exists (nvalid bits 16..23) were done by k4_lag0 and are left alone
 template <int NL, bool FAST = false>
 __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
     const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_grp *__restrict__ grps,
-    int G, float *__restrict__ p_out) {
+    int G, float *__restrict__ p_out, int skip_tabled) {
   constexpr int PPW = 16;                  // (group, symbol) pairs per wavefront, 4 tone lanes each
   constexpr int NLP = (NL + 1) & ~1;       // lags per sample slot, padded to even (16-B aligned slots)
   constexpr int ROWDW = 32 * NLP + 4;      // dwords per pair row: [16 samples][NLP lags] float2 + 16 B pad
@@ -304,8 +305,10 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
   const int sb = min(PPW, UWSPR_NSYM - iA0);  // pairs < sb belong to group gA
   const dev_grp A = grps[gA];
   const dev_grp Bg = grps[min(gA + 1, G - 1)];
-  const bool okA = A.frame >= 0 && A.frame < nframes;
-  const bool okB = (gA + 1 < G) && Bg.frame >= 0 && Bg.frame < nframes;
+  const bool doneA = skip_tabled && ((A.nvalid >> 16) & 0xff) != 0, doneB = skip_tabled && ((Bg.nvalid >> 16) & 0xff) != 0;
+  const bool okA = A.frame >= 0 && A.frame < nframes && !doneA;
+  const bool okB = (gA + 1 < G) && Bg.frame >= 0 && Bg.frame < nframes && !doneB;
+  if (skip_tabled && !okA && !(okB && UWSPR_NSYM - iA0 < PPW)) return;   // nothing of this wavefront is ours (wave-uniform)
   const int frA = okA ? A.frame : 0, frB = okB ? Bg.frame : 0;
   const int nvA = okA ? (A.nvalid & 0xff) : 0, nvB = okB ? (Bg.nvalid & 0xff) : 0;   // bit 8: see k4_ring
   // lag of slot l for the two groups; skipped groups / unused slots point at safe samples
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
     }
     // groups that are skipped produce zeros for their hypotheses
     const dev_grp &gy = mineA ? A : Bg;
-    if (!(mineA ? okA : okB) && (gy.nvalid & 0xff) > 0)
+    if (!(mineA ? okA : okB) && !(mineA ? doneA : doneB) && (gy.nvalid & 0xff) > 0)
       for (int l = 0; l < (gy.nvalid & 0xff) && l < NL; l++)
         p_out[((long long)(gy.hyp_base + (int)((gy.hmap >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
   }
@@ -485,10 +488,11 @@ void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   dim3 blk(64 * K4G_WAVES);
-  if (NL == 5 && c->fast_now) launch_timed(c, ps, (k4_group<5, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
-  else if (NL == 5) launch_timed(c, ps, k4_group<5>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
-  else if (NL == 6) launch_timed(c, ps, k4_group<6>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
-  else launch_timed(c, ps, k4_group<8>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po);
+  const int skip = c->group_skip_tabled ? 1 : 0;   // set around stage 0 when k4_lag0 took the tabled slots
+  if (NL == 5 && c->fast_now) launch_timed(c, ps, (k4_group<5, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, skip);
+  else if (NL == 5) launch_timed(c, ps, k4_group<5>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, skip);
+  else if (NL == 6) launch_timed(c, ps, k4_group<6>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, skip);
+  else launch_timed(c, ps, k4_group<8>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, skip);
 }
 
 // ---------------------------------------------------------------------------
@@ -963,6 +967,166 @@ __global__ __launch_bounds__(256) void k4_fstage(
         p_out[(((long long)slot * NF + q) * UWSPR_NSYM + own_i) * 4 + tone] =
             ieee_sqrtf(inp[q] * inp[q] + quad[q] * quad[q]);   // cc:211
   }
+}
+
+// S0 of the schedule (cc:409-415: five lags 64 samples apart at one frequency), sample-major, for the slots
+// whose frequency does not depend on the symbol (their phasor table exists: dev_grp::nvalid bits 16..23; the
+// others are left to k4_group).  The four computed lags of a symbol read windows that overlap by three quarters
+// (lag q covers samples [64 q, 64 q + 256) of the row's 448), so the row is streamed ONCE in 14 chunks of 32
+// samples and every staged sample feeds each lag whose window it lies in, against phasor step k = a - 64 q of
+// the slot's table (LDS, broadcast: the tone is wavefront-uniform) -- no recurrence, no per-lag reload.  The
+// fifth lag is the first one symbol later (k4_group's wrap): a 163rd, virtual row per slot supplies it for
+// symbol 161.  Rows are packed like k4_fpack's: 64 consecutive (slot, row) pairs per workgroup, four tone
+// wavefronts, at most two slots per workgroup.  Every accumulator still sees the reference's operation
+// sequence (cc:206-207); the table is the recurrence of cc:193-195, computed once per slot.
+constexpr int K4L_ROWS_PER_SLOT = UWSPR_NSYM + 1;
+
+template <int QMASK, bool FAST>
+__device__ __forceinline__ void k4_lag0_chunk(const float *__restrict__ smprow, const float4 *__restrict__ tabrow,
+                                              int a0, float (&inp)[4], float (&quad)[4]) {
+  // a0 = 32 c: stream position of the chunk's first sample; lag q sees it as step k = a0 - 64 q
+#pragma unroll
+  for (int k = 0; k < 32; k += 2) {
+    const float4 x = *reinterpret_cast<const float4 *>(&smprow[2 * k]);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (!((QMASK >> q) & 1)) continue;
+      const float4 ph = tabrow[(a0 - 64 * q + k) >> 1];      // (c, s) of steps k and k + 1 of lag q
+      k4_mac<FAST>(inp[q], quad[q], x.x, x.y, ph.x, ph.y);   // cc:206-207
+      k4_mac<FAST>(inp[q], quad[q], x.z, x.w, ph.z, ph.w);
+    }
+  }
+}
+
+template <bool FAST = false>
+__global__ __launch_bounds__(256) void k4_lag0(
+    const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_grp *__restrict__ grps,
+    int nslots, float *__restrict__ p_out, const float2 *__restrict__ ptab) {
+  constexpr int ROWS = 64, CH = 32, ROWDW = 2 * CH + 4, SEGS = 256 / CH, NR = ROWS / SEGS, NCHUNK = 14;
+  __shared__ __align__(16) float smp[ROWS * ROWDW];
+  __shared__ __align__(16) float4 tab[2][4][128];   // [slot A/B][tone][step pair]: the slot's whole table
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int tone = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long long total = (long long)nslots * K4L_ROWS_PER_SLOT;
+  const long long g0 = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * ROWS;
+  if (g0 >= total) return;  // workgroup-uniform
+
+  const int slotA = (int)(g0 / K4L_ROWS_PER_SLOT);
+  const int rA0 = (int)(g0 - (long long)slotA * K4L_ROWS_PER_SLOT);
+  const int sb = min(ROWS, K4L_ROWS_PER_SLOT - rA0);      // rows < sb belong to slot A
+  const bool hasB = sb < ROWS && slotA + 1 < nslots;
+  const int slotB = hasB ? slotA + 1 : slotA;
+  const dev_grp A = grps[slotA], Bg = grps[slotB];
+  // a slot is taken here only if it is live AND has its table (else k4_group's launch has it)
+  const int selA = (A.nvalid >> 16) & 0xff, selB = (Bg.nvalid >> 16) & 0xff;
+  const bool doA = A.frame >= 0 && A.frame < nframes && selA != 0;
+  const bool doB = hasB && Bg.frame >= 0 && Bg.frame < nframes && selB != 0;
+  if (!doA && !doB) return;  // workgroup-uniform
+
+  // ---- the slots' tables -> LDS (8 KB each: 16 bytes x 2 loads per thread and slot)
+#pragma unroll
+  for (int sl = 0; sl < 2; sl++) {
+    if (!(sl ? doB : doA)) continue;
+    const float4 *src = reinterpret_cast<const float4 *>(
+        ptab + ((size_t)(sl ? slotB : slotA) * kPtabPerSlot + ((sl ? selB : selA) - 1)) * kPtabFloat2);
+    float4 *dst = &tab[sl][0][0];
+    dst[tid] = src[tid];
+    dst[tid + 256] = src[tid + 256];
+  }
+
+  const int row = lane;
+  const bool mineA = row < sb;
+  const int own_r = mineA ? rA0 + row : row - sb;       // 0..161 real symbols, 162 the virtual row
+  const bool own_do = mineA ? doA : doB;
+  const bool valid = (g0 + row < total) && (mineA || hasB) && own_do;
+
+  // ---- loader: round r of a chunk = row SEGS r + tid/CH, sample tid%CH ----
+  const int kk = tid % CH, seg = tid / CH;
+  const float2 *fbA = frames + (long long)(doA ? A.frame : 0) * fstride;
+  const float2 *fbB = frames + (long long)(doB ? Bg.frame : 0) * fstride;
+  const int nA0 = A.lag[0] + 256 * rA0, nB0 = Bg.lag[0];
+  const bool interior = doA && (nA0 > 0) && (nA0 + 256 * (sb - 1) + 32 * NCHUNK < np) &&
+                        (sb >= ROWS || (doB && (nB0 > 0) && (nB0 + 256 * (ROWS - sb - 1) + 32 * NCHUNK < np)));
+  float2 stage[NR];
+  int nrow[NR];
+  bool rowB[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const int rw = SEGS * r + seg;
+    rowB[r] = rw >= sb;
+    nrow[r] = (rowB[r] ? nB0 + 256 * (rw - sb) : nA0 + 256 * rw) + kk;
+  }
+  auto load_chunk = [&](int c) {
+    if (interior) {
+#pragma unroll
+      for (int r = 0; r < NR; r++) stage[r] = (rowB[r] ? fbB : fbA)[nrow[r] + CH * c];
+    } else {
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+        const int n = nrow[r] + CH * c;
+        const bool inr = (n > 0) && (n < np);      // cc:205, sample 0 excluded
+        const float2 v = (rowB[r] ? fbB : fbA)[min(max(n, 0), np - 1)];
+        stage[r] = inr ? v : make_float2(0.0f, 0.0f);
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+      *reinterpret_cast<float2 *>(&smp[(SEGS * r + seg) * ROWDW + 2 * kk]) = stage[r];
+  };
+
+  float inp[4], quad[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { inp[q] = 0.0f; quad[q] = 0.0f; }
+  const float *smprow = &smp[row * ROWDW];
+  const float4 *tabrow = &tab[mineA ? 0 : 1][tone][0];
+
+  load_chunk(0);
+  // lag q is inside its window for chunks 2 q .. 2 q + 7: seven phases of two chunks with a fixed set of lags
+  auto phase = [&](auto mask_tag, int c0) {
+    constexpr int QMASK = decltype(mask_tag)::value;
+    for (int c = c0; c < c0 + 2; c++) {
+      __syncthreads();              // the previous chunk has been read by everyone (first: the tables are in)
+      store_chunk();
+      __syncthreads();
+      load_chunk(min(c + 1, NCHUNK - 1));   // in flight during the arithmetic
+      k4_lag0_chunk<QMASK, FAST>(smprow, tabrow, 32 * c, inp, quad);
+    }
+  };
+  phase(std::integral_constant<int, 0x1>{}, 0);
+  phase(std::integral_constant<int, 0x3>{}, 2);
+  phase(std::integral_constant<int, 0x7>{}, 4);
+  phase(std::integral_constant<int, 0xf>{}, 6);
+  phase(std::integral_constant<int, 0xe>{}, 8);
+  phase(std::integral_constant<int, 0xc>{}, 10);
+  phase(std::integral_constant<int, 0x8>{}, 12);
+
+  if (valid) {
+    const int hb = mineA ? A.hyp_base : Bg.hyp_base;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const float pj = ieee_sqrtf(inp[q] * inp[q] + quad[q] * quad[q]);   // cc:211
+      if (own_r < UWSPR_NSYM) p_out[((long long)(hb + q) * UWSPR_NSYM + own_r) * 4 + tone] = pj;
+      // the wrap: (first lag, symbol r) is also (fifth lag, symbol r - 1)
+      if (q == 0 && own_r >= 1) p_out[((long long)(hb + 4) * UWSPR_NSYM + own_r - 1) * 4 + tone] = pj;
+    }
+  }
+}
+
+void launch_tonecorr_lag0(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int nslots,
+                          int64_t nhyps, float4 *p) {
+  if (nslots <= 0) return;
+  prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
+  const unsigned wgs = (unsigned)(((long long)nslots * K4L_ROWS_PER_SLOT + 63) / 64);
+  if (c->fast_now)
+    launch_timed(c, ps, k4_lag0<true>, dim3(wgs), dim3(256), 0, (const float2 *)frames, c->fstride, c->np, B, grps,
+                 nslots, (float *)p, (const float2 *)c->d_ptab);
+  else
+    launch_timed(c, ps, k4_lag0<false>, dim3(wgs), dim3(256), 0, (const float2 *)frames, c->fstride, c->np, B, grps,
+                 nslots, (float *)p, (const float2 *)c->d_ptab);
 }
 
 // Packed form of the frequency stage: the (slot, symbol) pairs of the whole launch are flattened and a

@@ -112,6 +112,8 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->use_fstage = !(getenv("UWSPR_K4_FSTAGE") && atoi(getenv("UWSPR_K4_FSTAGE")) == 0);
   c->reuse_centre = !(getenv("UWSPR_K4_REUSE") && atoi(getenv("UWSPR_K4_REUSE")) == 0);
   c->use_k5_lds = !(getenv("UWSPR_K5_LDS") && atoi(getenv("UWSPR_K5_LDS")) == 0);
+  c->k4_lag0 = !(getenv("UWSPR_K4_LAG0") && atoi(getenv("UWSPR_K4_LAG0")) == 0);
+  c->group_skip_tabled = false; c->cands_from_fdr = false;
   c->k4_fpack = !(getenv("UWSPR_K4_FPACK") && atoi(getenv("UWSPR_K4_FPACK")) == 0);
   c->k4f_onegen = !(getenv("UWSPR_K4F_ONEGEN") && atoi(getenv("UWSPR_K4F_ONEGEN")) == 0);
   c->k5_s5_lanes = getenv("UWSPR_K5_S5_LANES") && atoi(getenv("UWSPR_K5_S5_LANES")) != 0;
@@ -786,6 +788,17 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
     else if (c->use_fstage && (s == 1 || s == 4)) launch_tonecorr_fstage(c, dframes, B, h, (int)nslots, H, c->d_p);
     else if (use_groups && s == 3 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)nslots, 5, 16, H, c->d_p, 1);
     else if (use_groups && s == 5 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, 8, H, c->d_p, 3);
+    else if (use_groups && s == 0 && c->k4_lag0 && c->use_ptab) {
+      // the slots whose frequency does not depend on the symbol (they have their phasor table) sample-major;
+      // the others -- drifting linear candidates -- through the lag-group kernel, which skips the former.
+      // Candidates from this context's own FDR with maxdrift = 0 have no drift: that launch is not needed.
+      launch_tonecorr_lag0(c, dframes, B, c->d_grps, (int)nslots, H, c->d_p);
+      if (!(c->cands_from_fdr && c->p.maxdrift == 0)) {
+        c->group_skip_tabled = true;
+        launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)nslots, 5, H, c->d_p, 1);
+        c->group_skip_tabled = false;
+      }
+    }
     else if (use_groups && (s == 0 || s == 3)) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)nslots, 5, H, c->d_p, 1);
     else if (use_groups && s == 5) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, H, c->d_p, 3);
     else launch_tonecorr(c, dframes, B, h, H, c->d_p);
@@ -821,6 +834,7 @@ extern "C" int uwspr_demod_batch(uwspr_ctx *c, const float *frames, int B, int w
     HIPCHK(c, hipMemcpyAsync(c->d_tmpn, npk, (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     dc = c->d_tmpc; dn = c->d_tmpn;
   }
+  c->cands_from_fdr = false;   // the caller's candidates: any drift
   rc = run_schedule(c, d, B, dc, dn, cand_stride, max_per_frame);
   if (!rc) rc = copy_out(c, out, c->d_dout, (size_t)B * max_per_frame * sizeof(uwspr_demod_out), host_recs ? UWSPR_HOST : UWSPR_DEVICE);
   if (!rc && !host_recs) c->last_sched_out = out;   // a device caller's copy of the records is what a device resume patches
@@ -841,6 +855,7 @@ extern "C" int uwspr_pipeline_batch(uwspr_ctx *c, const float *frames, int B, in
   // device callers get the results written straight into their buffers
   const bool dev = where == UWSPR_DEVICE;
   if ((rc = run_fdr(c, d, B, dev ? cands : nullptr, (dev && cands) ? npk : nullptr))) return rc;
+  c->cands_from_fdr = true;
   if ((rc = run_schedule(c, d, B, c->cur_cands, c->cur_npk, c->fc.maxfreqs, max_per_frame,
                          dev ? out : nullptr))) return rc;
   c->last_per_frame = max_per_frame;

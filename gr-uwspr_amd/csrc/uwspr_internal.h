@@ -158,6 +158,9 @@ struct uwspr_ctx {
   // UWSPR_FAST_SEARCH=1: stages S0..S4 of the schedule with fused multiply-adds and shuffle-tree sums (not
   // the reference's arithmetic; S5 and every other entry point stay exact).  fast_now: set around those launches.
   bool fast_search, fast_now;
+  bool k4_lag0;          // S0 through the sample-major packed form for the slots that have a phasor table (UWSPR_K4_LAG0=0: k4_group)
+  bool group_skip_tabled;   // set around the S0 k4_group launch that follows k4_lag0
+  bool cands_from_fdr;   // the schedule call's candidates are this context's own FDR output (drift within +-maxdrift)
   bool k4_fpack;         // S1/S4 through the packed form (64 consecutive (slot, symbol) pairs per workgroup); UWSPR_K4_FPACK=0: k4_fstage
   bool k4f_onegen;       // k4_fstage: wavefront 0 generates all four tones' phasor tables (UWSPR_K4F_ONEGEN=0: each its own)
   bool k5_s5_lanes;      // UWSPR_K5_S5_LANES=1: the schedule's stage-5 fold through the lanes form (measured slower: 68 long wavefronts)
@@ -207,6 +210,8 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
 // lag-group form: G groups, each instantiated for NL in {5, 6, 8} lags
 void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
                             int NL, int64_t nhyps, float4 *p, int groups_per_slot = 1);
+void launch_tonecorr_lag0(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int nslots,
+                          int64_t nhyps, float4 *p);
 void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int nslots,
                             int64_t nhyps, float4 *p);
 void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,

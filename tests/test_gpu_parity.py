@@ -311,6 +311,7 @@ def test_schedule_without_lag_groups_is_identical(G, frames, vec, monkeypatch):
         monkeypatch.setenv("UWSPR_K5_S5_LANES", reuse)       # stage-5 fold: one lane per try vs one wavefront per try
         monkeypatch.setenv("UWSPR_K4_PTAB", k5lds)           # lag stages: phasor tables vs per-lane recurrences
         monkeypatch.setenv("UWSPR_K4_FPACK", groups)         # S1/S4: packed (slot, symbol) pairs vs three parts of 54 symbols
+        monkeypatch.setenv("UWSPR_K4_LAG0", ring)            # S0: sample-major packed form vs the lag-group kernel
         monkeypatch.setenv("UWSPR_SCHED_FUSED", fused)       # one workgroup per candidate (k6_sched) vs staged launches
         monkeypatch.setenv("UWSPR_K4_GROUPS", groups)        # lag sweeps: k4_group vs k4_tonecorr
         monkeypatch.setenv("UWSPR_K4_STAGE_GRID", stage_grid)  # freq/drift stages: k4_grid vs k4_tonecorr
