@@ -985,21 +985,28 @@ template <int QMASK, bool FAST>
 __device__ __forceinline__ void k4_lag0_chunk(const float *__restrict__ smprow, const float4 *__restrict__ tabrow,
                                               int a0, float (&inp)[4], float (&quad)[4]) {
   // a0 = 32 c: stream position of the chunk's first sample; lag q sees it as step k = a0 - 64 q
+  // eight steps per trip of a rolled loop: fully unrolled the scheduler hoists a chunk's LDS reads above its
+  // arithmetic (512 registers and scratch)
+#pragma unroll 1
+  for (int k0 = 0; k0 < 32; k0 += 8) {
 #pragma unroll
-  for (int k = 0; k < 32; k += 2) {
-    const float4 x = *reinterpret_cast<const float4 *>(&smprow[2 * k]);
+    for (int kk = 0; kk < 8; kk += 2) {
+      const int k = k0 + kk;
+      const float4 x = *reinterpret_cast<const float4 *>(&smprow[2 * k]);
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      if (!((QMASK >> q) & 1)) continue;
-      const float4 ph = tabrow[(a0 - 64 * q + k) >> 1];      // (c, s) of steps k and k + 1 of lag q
-      k4_mac<FAST>(inp[q], quad[q], x.x, x.y, ph.x, ph.y);   // cc:206-207
-      k4_mac<FAST>(inp[q], quad[q], x.z, x.w, ph.z, ph.w);
+      for (int q = 0; q < 4; q++) {
+        if (!((QMASK >> q) & 1)) continue;
+        const float4 ph = tabrow[(a0 - 64 * q + k) >> 1];      // (c, s) of steps k and k + 1 of lag q
+        k4_mac<FAST>(inp[q], quad[q], x.x, x.y, ph.x, ph.y);   // cc:206-207
+        k4_mac<FAST>(inp[q], quad[q], x.z, x.w, ph.z, ph.w);
+      }
     }
   }
 }
 
 template <bool FAST = false>
-__global__ __launch_bounds__(256) void k4_lag0(
+__global__ __launch_bounds__(256, 4) void k4_lag0(   // 4 wavefronts per SIMD: <= 128 VGPRs (left alone the scheduler hoists a
+                                                      // whole chunk's LDS reads above its arithmetic: 512 registers + scratch)
     const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_grp *__restrict__ grps,
     int nslots, float *__restrict__ p_out, const float2 *__restrict__ ptab) {
   constexpr int ROWS = 64, CH = 32, ROWDW = 2 * CH + 4, SEGS = 256 / CH, NR = ROWS / SEGS, NCHUNK = 14;
@@ -1088,6 +1095,7 @@ __global__ __launch_bounds__(256) void k4_lag0(
   // lag q is inside its window for chunks 2 q .. 2 q + 7: seven phases of two chunks with a fixed set of lags
   auto phase = [&](auto mask_tag, int c0) {
     constexpr int QMASK = decltype(mask_tag)::value;
+#pragma unroll 1
     for (int c = c0; c < c0 + 2; c++) {
       __syncthreads();              // the previous chunk has been read by everyone (first: the tables are in)
       store_chunk();

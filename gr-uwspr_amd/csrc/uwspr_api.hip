@@ -761,11 +761,12 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
   if ((rc = ensure(c, &c->d_dout, &c->cap_dout, nslots))) return rc;
   c->cur_dout = user_out ? user_out : c->d_dout;
   dev_hyp *half[2] = {c->d_hyps, c->d_hyps + nslots * UWSPR_NJIG};
-  launch_sched_init(c, dcands, dnpk, cand_stride, B, per_frame);
-  const bool lazy = njig < UWSPR_NJIG;   // only tries idt < njig of stage 5, packed njig per slot
-  // the stage winner's magnitudes, carried from stage to stage (try 0 of stage 5 repeats the stage-4 winner)
+  // the stage winner's magnitudes, carried from stage to stage (try 0 of stage 5 repeats the stage-4 winner),
+  // and the phasor tables of the lag stages (set A is built by the init kernel: both before it)
   if ((rc = ensure(c, &c->d_pwin, &c->cap_pwin, nslots * UWSPR_NSYM * 4))) return rc;
   if ((rc = ensure(c, &c->d_ptab, &c->cap_ptab, nslots * kPtabPerSlot * kPtabFloat2))) return rc;
+  launch_sched_init(c, dcands, dnpk, cand_stride, B, per_frame);
+  const bool lazy = njig < UWSPR_NJIG;   // only tries idt < njig of stage 5, packed njig per slot
   for (int s = 0; s < 6; s++) {
     c->fast_now = c->fast_search && s < 5;   // S5 (the soft symbols) is always the reference's arithmetic
     const int H = (int)(nslots * (s == 5 ? njig : hpc[s]));

@@ -328,6 +328,41 @@ def test_schedule_without_lag_groups_is_identical(G, frames, vec, monkeypatch):
     assert (outs[0][:, 0]["symbols"] == vec["demod_symbols"]).all()
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_whole_pipeline_on_fresh_and_growing_contexts(G, frames, monkeypatch, fused):
+    """uwspr_pipeline_batch (candidates straight from the context's own FDR: the stage-0 lag-group launch is then
+    left out when maxdrift = 0) in both schedule forms: the FIRST call of a fresh context, a larger batch after a
+    small one (every per-slot scratch buffer grows between the calls) and the small one again give the bytes of the
+    reference configuration (fused form, one context per call), host and device frames, eager and lazy + resume."""
+    import torch
+    big = np.concatenate([frames, frames[::-1], frames, frames[1:3]])     # 14 frames
+    monkeypatch.setenv("UWSPR_SCHED_FUSED", "1")
+    ref = {}
+    for name, fr in (("small", frames[:3]), ("big", big)):
+        c = G.Context()
+        try:
+            ref[name] = c.pipeline_batch(fr, max_per_frame=2)
+        finally:
+            c.close()
+    monkeypatch.setenv("UWSPR_SCHED_FUSED", fused)
+    c = G.Context()
+    try:
+        for name, fr in (("small", frames[:3]), ("big", big), ("small", frames[:3])):
+            cands, out = c.pipeline_batch(fr, max_per_frame=2)
+            assert out.tobytes() == ref[name][1].tobytes(), (fused, name)
+            for a, b in zip(cands, ref[name][0]):
+                assert a.tobytes() == b.tobytes()
+        dev = torch.from_numpy(big).cuda()
+        cands, out = c.pipeline_batch(dev, max_per_frame=2)
+        assert out.tobytes() == ref["big"][1].tobytes()
+        c.set_tries(1)
+        c.pipeline_batch(big, max_per_frame=2)
+        res = c.demod_resume(big, np.ones((14, 2), np.uint8), None, max_per_frame=2)
+        assert res.tobytes() == ref["big"][1].tobytes()
+    finally:
+        c.close()
+
+
 def test_pipeline_device_pointers_equal_host_pointers(ctx, G, frames):
     """The same batch through UWSPR_DEVICE pointers (HBM-resident, what bench.py times)."""
     import torch
