@@ -512,7 +512,8 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
                                                 dev_grp *__restrict__ grps,
                                                 uwspr_candidate *__restrict__ cent,
                                                 int32_t *__restrict__ cframe, bool reuse, int team = 0,
-                                                int njig = UWSPR_NJIG, int *wsrc = nullptr, bool tabs = false) {
+                                                int njig = UWSPR_NJIG, int *wsrc = nullptr, bool tabs = false,
+                                                bool fast = false) {
   // *wsrc (written by team 0): the input hypothesis whose tone magnitudes are now those of the state's
   // (f1, shift1, drift1) -- the stage winner -- or -1: the winner is the hypothesis that was marked known
   // (its magnitudes are the ones already kept) or nobody won.  The workgroup copies them to the slot's kept
@@ -599,7 +600,9 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     }
     // try 0 is (f1, shift1, drift1): the hypothesis that just won stage 4 (cc:457-463 with idt = 0) -- known
     // when one did: its magnitudes are the kept ones, K4 leaves it out, the fold reads the kept row
-    const bool known0 = reuse && st.worth && st.sync1 > -1e30f;
+    // (UWSPR_FAST_SEARCH: the kept magnitudes come from the fused-multiply-add stages; stage 5 is always the
+    // reference's arithmetic, so try 0 is correlated again there)
+    const bool known0 = reuse && !fast && st.worth && st.sync1 > -1e30f;
     st.cknown = known0 ? 1 : 0;
     if (team < njig) {
       const int idt = team;
@@ -687,9 +690,9 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
   __syncthreads();
   if (STAGE == 5) {
     if (threadIdx.x < UWSPR_NJIG + 3)
-      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x, njig, &s_wsrc, ptab != nullptr);
+      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x, njig, &s_wsrc, ptab != nullptr, FAST);
   } else if (threadIdx.x == 0) {
-    sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, 0, njig, &s_wsrc, ptab != nullptr);
+    sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, 0, njig, &s_wsrc, ptab != nullptr, FAST);
   }
   __syncthreads();
   if (STAGE == 3 && ptab && threadIdx.x < 64) {   // table set B around the f1 the fine stages start from
