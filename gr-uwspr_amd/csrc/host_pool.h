@@ -41,6 +41,10 @@ class host_pool {
   int n_ = 0, chunk_ = 1, tickets_ = 0, active_ = 0;
 };
 
+// one jiggered try of a candidate: the gates of cc:470 and, if it passes them, de-interleave + Fano.
+// returns 1 decoded (message7 filled), 0 not decoded, -1 the try did not pass the gates (no Fano call)
+int decode_try(const uwspr_demod_out *d, int idt, int8_t *message7);
+
 // uwspr_decode_candidate from try `first` on
 int decode_candidate_from(const uwspr_demod_out *d, int first, int8_t *message7, int32_t *idt_used,
                           int *fano_calls = nullptr);

@@ -173,6 +173,20 @@ extern "C" int uwspr_fano_decode(const uint8_t *symbols, uint8_t *data, uint32_t
   return i >= budget ? -1 : 0;
 }
 
+int uwspr::decode_try(const uwspr_demod_out *d, int idt, int8_t *message7) {
+  const float minsync2 = 0.12f;
+  const float minrms = (float)(52.0 * (50 / 64.0));
+  if (!d->worth_a_try || idt < 0 || idt >= UWSPR_NJIG) return -1;
+  if (!(d->jig_sync[idt] > minsync2 && d->jig_rms[idt] > minrms)) return -1;   // cc:470
+  uint8_t sym[UWSPR_NSYM], data[11];
+  memset(data, 0, sizeof(data));
+  for (int p = 0; p < UWSPR_NSYM; p++) sym[p] = d->symbols[idt][kDeint.src[p]];
+  uint32_t metric, cycles, maxnp;
+  if (uwspr_fano_decode(sym, data, &metric, &cycles, &maxnp, 60, 10000) != 0) return 0;
+  for (int i = 0; i < 7; i++) message7[i] = (int8_t)data[i];
+  return 1;
+}
+
 // cc:457-490 from try `first` on (the tries before it have been attempted already: the lazy flow)
 int uwspr::decode_candidate_from(const uwspr_demod_out *d, int first, int8_t *message7, int32_t *idt_used,
                                  int *fano_calls) {

@@ -49,6 +49,9 @@ struct pipe_lane {
   std::vector<int32_t> idt;          // [B*per]
   std::vector<int8_t> msg;           // [B*per][7]
   std::vector<int> redo;             // records resumed
+  std::vector<int> tasks;            // (record << 5) | try: the resumed tries, decoded in parallel
+  std::vector<uint8_t> task_ok;
+  std::vector<int8_t> task_msg;
 };
 
 double now_s() {
@@ -116,12 +119,12 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
   double t1 = now_s();
   auto valid = [&](int i) { const int b = i / per, j = i - b * per; return j < L.h_npk[b] && j < q->maxfreqs; };
   // cc:457-490 on what the first pass produced (try 0 alone in the lazy flow)
-  std::atomic<long long> calls(0);
+  std::atomic<long long> calls(0), fails(0);
   q->pool->run(nrec, q->o.host_threads, [&](int i) {
     int32_t idt = -1;
     int r = 0, nc = 0;
     if (valid(i)) r = decode_candidate_from(&L.h_out[i], 0, &L.msg[7 * (size_t)i], &idt, &nc);
-    if (nc) calls.fetch_add(nc, std::memory_order_relaxed);
+    if (nc) { calls.fetch_add(nc, std::memory_order_relaxed); fails.fetch_add(nc - r, std::memory_order_relaxed); }
     if (!r) memset(&L.msg[7 * (size_t)i], 0, 7);
     L.dec[i] = (uint8_t)r;
     L.idt[i] = idt;
@@ -149,16 +152,31 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
     PHIP(q, hipEventRecord(L.ev_done, L.stream));
     PHIP(q, hipEventSynchronize(L.ev_done));
     t3 = now_s();
-    q->pool->run((int)L.redo.size(), q->o.host_threads, [&](int k) {
-      const int i = L.redo[k];
-      int32_t idt = -1;
-      int nc = 0;
-      const int r = decode_candidate_from(&L.h_out[i], 1, &L.msg[7 * (size_t)i], &idt, &nc);
-      if (nc) calls.fetch_add(nc, std::memory_order_relaxed);
-      if (!r) memset(&L.msg[7 * (size_t)i], 0, 7);
-      L.dec[i] = (uint8_t)r;
-      L.idt[i] = idt;
+    // The reference walks a candidate's tries one after the other and stops at the first that decodes
+    // (cc:457-490).  A try that does not decode runs Fano to its 10000-cycles-per-bit time-out (~4 ms of one
+    // core), so a candidate nothing decodes would hold ONE thread for 16 time-outs while the pool idles.
+    // The tries are independent decodes: all (candidate, try) pairs go to the pool at once and the first
+    // try in the reference's order that decoded is the answer -- the same message and idt; the tries after
+    // a decoding one are work the reference would not have done.
+    L.tasks.clear();
+    for (int i : L.redo)
+      for (int idt = 1; idt < UWSPR_NJIG; idt++) L.tasks.push_back((i << 5) | idt);
+    L.task_ok.assign(L.tasks.size(), 0);
+    L.task_msg.resize(L.tasks.size() * 7);
+    q->pool->run((int)L.tasks.size(), q->o.host_threads, [&](int t) {
+      const int i = L.tasks[t] >> 5, idt = L.tasks[t] & 31;
+      const int r = decode_try(&L.h_out[i], idt, &L.task_msg[7 * (size_t)t]);
+      if (r >= 0) calls.fetch_add(1, std::memory_order_relaxed);
+      if (r == 0) fails.fetch_add(1, std::memory_order_relaxed);
+      L.task_ok[t] = (uint8_t)(r > 0);
     });
+    for (size_t t = 0; t < L.tasks.size(); t++) {   // tasks are in (candidate, try) order
+      const int i = L.tasks[t] >> 5, idt = L.tasks[t] & 31;
+      if (L.task_ok[t] && !L.dec[i]) {
+        L.dec[i] = 1; L.idt[i] = idt;
+        memcpy(&L.msg[7 * (size_t)i], &L.task_msg[7 * t], 7);
+      }
+    }
   }
   double t4 = now_s();
   int ncand = 0, ndec = 0;
@@ -184,7 +202,7 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
     }
     q->st.frames += B; q->st.batches += 1; q->st.candidates += ncand; q->st.decoded += ndec;
     q->st.resumed += (int64_t)L.redo.size();
-    q->st.fano_calls += calls.load(); q->st.fano_timeouts += calls.load() - ndec;
+    q->st.fano_calls += calls.load(); q->st.fano_timeouts += fails.load();   // (tries run after a decoding one count as calls)
     q->st.gpu_wait_s += (t1 - t0);
     q->st.fano_s += (t2 - t1) + (t4 - t3);
     q->st.resume_s += (t3 - t2);
