@@ -22,23 +22,31 @@ class host_pool {
   explicit host_pool(int nthreads);   // <= 0: host_cpu_share()
   ~host_pool();
   int size() const { return nworkers_ + 1; }
-  // fn(i) for i in [0, n) on at most max_threads threads (<= 0: all); returns when all are done
+  // fn(i) for i in [0, n) on at most max_threads threads (<= 0: all), the caller among them; returns when all
+  // are done.  Callers on different threads run their jobs side by side.
   void run(int n, int max_threads, const std::function<void(int)> &fn);
   static host_pool &shared();
 
  private:
+  struct job {
+    const std::function<void(int)> *fn = nullptr;
+    int n = 0, chunk = 1, max_threads = 1;
+    std::atomic<int> next{0};
+    int threads = 0, done = 0;   // under m_
+  };
   void worker();
-  void drain();
+  int drain(job &j);
+  job *pick();
+  int count_pending();
   std::vector<std::thread> threads_;
   int nworkers_ = 0;
-  std::mutex m_, job_m_;
+  std::mutex m_;
   std::condition_variable cv_, cv_done_;
-  uint64_t gen_ = 0;
-  std::atomic<uint64_t> gen_a_{0};   // gen_, readable without the lock (the workers' spin)
+  std::vector<job *> jobs_;            // jobs in the pool (each lives on its caller's stack until it is done)
+  size_t rr_ = 0;
+  std::atomic<uint64_t> gen_a_{0};     // bumped per job: the workers' spin looks at it without the lock
+  std::atomic<int> pending_{0};        // jobs with items still to hand out
   bool stop_ = false;
-  const std::function<void(int)> *fn_ = nullptr;
-  std::atomic<int> next_{0};
-  int n_ = 0, chunk_ = 1, tickets_ = 0, active_ = 0;
 };
 
 // one jiggered try of a candidate: the gates of cc:470 and, if it passes them, de-interleave + Fano.

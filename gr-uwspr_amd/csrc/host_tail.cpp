@@ -261,58 +261,91 @@ host_pool::~host_pool() {
   for (auto &t : threads_) t.join();
 }
 
-void host_pool::drain() {
+// items of one job until none is left to hand out; returns how many this thread ran
+int host_pool::drain(job &j) {
+  int ran = 0;
   for (;;) {
-    const int i0 = next_.fetch_add(chunk_, std::memory_order_relaxed);
-    if (i0 >= n_) break;
-    const int i1 = i0 + chunk_ < n_ ? i0 + chunk_ : n_;
-    for (int i = i0; i < i1; i++) (*fn_)(i);
+    const int i0 = j.next.fetch_add(j.chunk, std::memory_order_relaxed);
+    if (i0 >= j.n) break;
+    const int i1 = i0 + j.chunk < j.n ? i0 + j.chunk : j.n;
+    for (int i = i0; i < i1; i++) (*j.fn)(i);
+    ran += i1 - i0;
   }
+  return ran;
+}
+
+// a job that still has items to hand out and room for another thread (m_ held)
+host_pool::job *host_pool::pick() {
+  const size_t nj = jobs_.size();
+  for (size_t k = 0; k < nj; k++) {
+    job *j = jobs_[(rr_ + k) % nj];
+    if (j->next.load(std::memory_order_relaxed) < j->n && j->threads < j->max_threads) {
+      rr_ = (rr_ + k + 1) % nj;   // the next worker looks at the next job first: jobs share the pool
+      return j;
+    }
+  }
+  return nullptr;
 }
 
 void host_pool::worker() {
-  uint64_t seen = 0;
   for (;;) {
     // a short spin first (no lock): between the batches of a busy pipeline the next job is microseconds away
-    for (int spin = 0; spin < 200 && gen_a_.load(std::memory_order_acquire) == seen; spin++) __builtin_ia32_pause();
+    const uint64_t seen = gen_a_.load(std::memory_order_acquire);
+    for (int spin = 0; spin < 200 && gen_a_.load(std::memory_order_acquire) == seen && pending_.load(std::memory_order_relaxed) == 0; spin++)
+      __builtin_ia32_pause();
+    job *j;
     {
       std::unique_lock<std::mutex> lk(m_);
-      cv_.wait(lk, [&]() { return gen_ != seen || stop_; });
+      cv_.wait(lk, [&]() { return stop_ || (j = pick()) != nullptr; });
       if (stop_) return;
-      seen = gen_;
-      if (tickets_ <= 0) continue;   // this job wants fewer threads
-      tickets_--;
-      active_++;
+      j->threads++;
     }
-    drain();
+    const int ran = drain(*j);
     {
       std::lock_guard<std::mutex> lk(m_);
-      active_--;
+      j->threads--;
+      j->done += ran;
+      if (j->next.load(std::memory_order_relaxed) >= j->n) pending_.store(count_pending(), std::memory_order_relaxed);
     }
     cv_done_.notify_all();
   }
 }
 
+int host_pool::count_pending() {   // jobs with items still to hand out (m_ held)
+  int c = 0;
+  for (job *j : jobs_) c += j->next.load(std::memory_order_relaxed) < j->n;
+  return c;
+}
+
+// Several callers may have jobs in the pool at once (the pipe's coordinators: the Fano time-outs of one batch
+// -- milliseconds each -- leave most threads idle, the next batch's decodes fill them).  Items are handed out
+// per job by an atomic counter; a worker takes the next job that has items left and room for a thread.
 void host_pool::run(int n, int max_threads, const std::function<void(int)> &fn) {
   if (n <= 0) return;
-  std::lock_guard<std::mutex> job(job_m_);   // one job at a time
+  job j;
+  j.fn = &fn; j.n = n;
   int want = max_threads > 0 ? max_threads : nworkers_ + 1;
   if (want > n) want = n;
+  j.max_threads = want;
+  j.chunk = n / (8 * want) > 0 ? n / (8 * want) : 1;
+  if (j.chunk > 16) j.chunk = 16;
   {
     std::lock_guard<std::mutex> lk(m_);
-    fn_ = &fn; n_ = n; next_.store(0);
-    chunk_ = n / (8 * want) > 0 ? n / (8 * want) : 1;
-    if (chunk_ > 16) chunk_ = 16;
-    tickets_ = want - 1 < nworkers_ ? want - 1 : nworkers_;
-    gen_++;
-    gen_a_.store(gen_, std::memory_order_release);
+    jobs_.push_back(&j);
+    j.threads = 1;   // the caller
+    pending_.store(count_pending(), std::memory_order_relaxed);
+    gen_a_.fetch_add(1, std::memory_order_release);
   }
   if (want > 1) cv_.notify_all();
-  drain();
+  const int ran = drain(j);
   std::unique_lock<std::mutex> lk(m_);
-  tickets_ = 0;   // late wakers find the job finished
-  cv_done_.wait(lk, [&]() { return active_ == 0; });
-  fn_ = nullptr;
+  j.threads--;
+  j.done += ran;
+  cv_done_.wait(lk, [&]() { return j.done >= j.n && j.threads == 0; });
+  for (size_t k = 0; k < jobs_.size(); k++)
+    if (jobs_[k] == &j) { jobs_.erase(jobs_.begin() + k); break; }
+  if (rr_ >= jobs_.size()) rr_ = 0;
+  pending_.store(count_pending(), std::memory_order_relaxed);
 }
 
 host_pool &host_pool::shared() {

@@ -6,7 +6,8 @@
 //   acquire / fill / commit  ------>  H2D of new samples
 //   batch complete: view in place --------------------->   K1 K2 K3, schedule (try 0),
 //                                                          D2H of records, event  ---->  wait event
-//   (next batch: lane k+1 ...)                                                           Fano on try 0 (pool)
+//   (next batch: lane k+1 ...)                                                           Fano on try 0 (pool; one
+//                                                                                        coordinator per lane)
 //                                                          resume (tries 1..16) <------  for what did not decode
 //                                                          D2H, event            ---->   Fano on tries 1..16
 //                                                                                        results in frame order
@@ -41,7 +42,10 @@ struct pipe_lane {
   uwspr_candidate *h_cands = nullptr; int32_t *h_npk = nullptr; uwspr_demod_out *h_out = nullptr; uint8_t *h_need = nullptr;
   hipEvent_t ev_done = nullptr;
   // the batch in flight
-  bool busy = false;
+  bool busy = false;       // taken by the producer, until its records have been emitted
+  bool launched = false;   // its GPU work is enqueued: the lane's coordinator may pick it up
+  int64_t seq = 0;         // batch number (emission order)
+  std::vector<uwspr_decode> recs;   // the batch's records, built by the coordinator, emitted in batch order
   int B = 0, stride = 0;
   const float *frames = nullptr;
   int64_t frame0 = 0, pos0 = -1;
@@ -80,11 +84,11 @@ struct uwspr_pipe {
   size_t stage_samples = 0;
 
   std::mutex m;
-  std::condition_variable cv_lane, cv_work, cv_done;
-  std::deque<int> inflight;
+  std::condition_variable cv_lane, cv_work, cv_done, cv_turn;
   std::deque<uwspr_decode> done;
   bool stop = false;
-  std::thread coord;
+  int64_t next_seq = 0, emit_seq = 0;     // batches launched / emitted (records leave in batch order)
+  std::vector<std::thread> coords;         // one coordinator per lane: the host tails of consecutive batches overlap
   host_pool *pool = nullptr;
   bool own_pool = false;
   uwspr_pipe_stats st;
@@ -180,8 +184,8 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
   }
   double t4 = now_s();
   int ncand = 0, ndec = 0;
+  L.recs.clear();
   {
-    std::lock_guard<std::mutex> lk(q->m);
     for (int b = 0; b < B; b++) {
       for (int j = 0; j < per; j++) {
         const int i = b * per + j;
@@ -196,10 +200,13 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
         d.f1 = o.f1; d.drift1 = o.drift1; d.sync1 = o.sync1; d.shift1 = o.shift1; d.worth_a_try = o.worth_a_try;
         d.decoded = L.dec[i]; d.idt = L.idt[i];
         memcpy(d.message, &L.msg[7 * (size_t)i], 7);
-        q->done.push_back(d);
+        L.recs.push_back(d);
         ncand++; ndec += L.dec[i];
       }
     }
+  }
+  {
+    std::lock_guard<std::mutex> lk(q->m);
     q->st.frames += B; q->st.batches += 1; q->st.candidates += ncand; q->st.decoded += ndec;
     q->st.resumed += (int64_t)L.redo.size();
     q->st.fano_calls += calls.load(); q->st.fano_timeouts += fails.load();   // (tries run after a decoding one count as calls)
@@ -210,23 +217,26 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
   return UWSPR_OK;
 }
 
-static void coordinator(uwspr_pipe *q) {
+static void coordinator(uwspr_pipe *q, int idx) {
   (void)hipSetDevice(q->device);
+  pipe_lane &L = q->lanes[idx];
   for (;;) {
-    int idx;
     {
       std::unique_lock<std::mutex> lk(q->m);
-      q->cv_work.wait(lk, [&]() { return q->stop || !q->inflight.empty(); });
-      if (q->inflight.empty()) return;   // stop, nothing left
-      idx = q->inflight.front();
+      q->cv_work.wait(lk, [&]() { return q->stop || L.launched; });
+      if (!L.launched) return;   // stop, nothing of this lane left
     }
-    pipe_lane &L = q->lanes[idx];
     (void)finish_batch(q, L);   // a failure is sticky in q->failed; the lane is released either way
     {
-      std::lock_guard<std::mutex> lk(q->m);
-      q->inflight.pop_front();
+      // records leave in batch order: wait for the batches before this one (they are on the other lanes)
+      std::unique_lock<std::mutex> lk(q->m);
+      q->cv_turn.wait(lk, [&]() { return q->emit_seq == L.seq; });
+      for (const uwspr_decode &d : L.recs) q->done.push_back(d);
+      q->emit_seq++;
+      L.launched = false;
       L.busy = false;
     }
+    q->cv_turn.notify_all();
     q->cv_lane.notify_all();
     q->cv_done.notify_all();
   }
@@ -259,9 +269,10 @@ static int launch(uwspr_pipe *q, pipe_lane &L, const float *frames, int B, int s
   if (ringbuf >= 0) q->ring.reader_done(ringbuf, L.ev_done);
   {
     std::lock_guard<std::mutex> lk(q->m);
-    q->inflight.push_back((int)(&L - q->lanes.data()));
+    L.seq = q->next_seq++;
+    L.launched = true;
   }
-  q->cv_work.notify_one();
+  q->cv_work.notify_all();
   return UWSPR_OK;
 }
 
@@ -291,14 +302,12 @@ extern "C" const char *uwspr_pipe_last_error(const uwspr_pipe *q) { return q ? q
 
 extern "C" void uwspr_pipe_close(uwspr_pipe *q) {
   if (!q) return;
-  if (q->coord.joinable()) {
-    {
-      std::lock_guard<std::mutex> lk(q->m);
-      q->stop = true;
-    }
-    q->cv_work.notify_all();
-    q->coord.join();
+  {
+    std::lock_guard<std::mutex> lk(q->m);
+    q->stop = true;
   }
+  q->cv_work.notify_all();
+  for (auto &t : q->coords) if (t.joinable()) t.join();
   (void)hipSetDevice(q->device);
   for (auto &L : q->lanes) {
     if (L.stream) (void)hipStreamSynchronize(L.stream);
@@ -369,7 +378,7 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
   }
   if (q->o.host_threads <= 0) q->o.host_threads = host_cpu_share() > 3 ? host_cpu_share() - 2 : 1;
   q->pool = &host_pool::shared();   // the process-wide pool; this pipe's jobs use host_threads of it
-  q->coord = std::thread(coordinator, q);
+  for (int k = 0; k < (int)q->lanes.size(); k++) q->coords.emplace_back(coordinator, q, k);
   return UWSPR_OK;
 }
 
