@@ -43,7 +43,8 @@ struct pipe_lane {
   hipEvent_t ev_done = nullptr;
   // the batch in flight
   bool busy = false;       // taken by the producer, until its records have been emitted
-  bool launched = false;   // its GPU work is enqueued: the lane's coordinator may pick it up
+  bool launched = false;   // its GPU work is enqueued: a coordinator may pick it up
+  bool claimed = false;    // a coordinator has
   int64_t seq = 0;         // batch number (emission order)
   std::vector<uwspr_decode> recs;   // the batch's records, built by the coordinator, emitted in batch order
   int B = 0, stride = 0;
@@ -52,6 +53,7 @@ struct pipe_lane {
   std::vector<uint8_t> dec;          // [B*per] decoded flags
   std::vector<int32_t> idt;          // [B*per]
   std::vector<int8_t> msg;           // [B*per][7]
+  std::vector<int> first;            // records whose first pass goes to the pool
   std::vector<int> redo;             // records resumed
   std::vector<int> tasks;            // (record << 5) | try: the resumed tries, decoded in parallel
   std::vector<uint8_t> task_ok;
@@ -124,15 +126,25 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
   auto valid = [&](int i) { const int b = i / per, j = i - b * per; return j < L.h_npk[b] && j < q->maxfreqs; };
   // cc:457-490 on what the first pass produced (try 0 alone in the lazy flow)
   std::atomic<long long> calls(0), fails(0);
-  q->pool->run(nrec, q->o.host_threads, [&](int i) {
+  // only the records that are worth a try go to the pool (a quiet stream has almost none: no wake-ups for it)
+  L.first.clear();
+  for (int i = 0; i < nrec; i++) {
+    L.dec[i] = 0; L.idt[i] = -1;
+    memset(&L.msg[7 * (size_t)i], 0, 7);
+    if (valid(i) && L.h_out[i].worth_a_try) L.first.push_back(i);
+  }
+  auto first_pass = [&](int k) {
+    const int i = L.first[k];
     int32_t idt = -1;
-    int r = 0, nc = 0;
-    if (valid(i)) r = decode_candidate_from(&L.h_out[i], 0, &L.msg[7 * (size_t)i], &idt, &nc);
+    int nc = 0;
+    const int r = decode_candidate_from(&L.h_out[i], 0, &L.msg[7 * (size_t)i], &idt, &nc);
     if (nc) { calls.fetch_add(nc, std::memory_order_relaxed); fails.fetch_add(nc - r, std::memory_order_relaxed); }
     if (!r) memset(&L.msg[7 * (size_t)i], 0, 7);
     L.dec[i] = (uint8_t)r;
     L.idt[i] = idt;
-  });
+  };
+  if (L.first.size() <= 2) for (size_t k = 0; k < L.first.size(); k++) first_pass((int)k);
+  else q->pool->run((int)L.first.size(), q->o.host_threads, first_pass);
   double t2 = now_s(), t3 = t2;
   L.redo.clear();
   if (!q->o.eager) {
@@ -217,23 +229,32 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
   return UWSPR_OK;
 }
 
-static void coordinator(uwspr_pipe *q, int idx) {
+// A coordinator takes the oldest launched batch nobody has taken yet, finishes it and emits its records when the
+// batches before it have been emitted.  ncoords threads run this loop (default: one per lane, so that the host
+// tails of consecutive batches overlap; UWSPR_PIPE_COORDS=1: strictly one batch after the other).
+static void coordinator(uwspr_pipe *q) {
   (void)hipSetDevice(q->device);
-  pipe_lane &L = q->lanes[idx];
   for (;;) {
+    pipe_lane *Lp = nullptr;
     {
       std::unique_lock<std::mutex> lk(q->m);
-      q->cv_work.wait(lk, [&]() { return q->stop || L.launched; });
-      if (!L.launched) return;   // stop, nothing of this lane left
+      q->cv_work.wait(lk, [&]() {
+        Lp = nullptr;
+        for (auto &L : q->lanes)
+          if (L.launched && !L.claimed && (!Lp || L.seq < Lp->seq)) Lp = &L;
+        return q->stop || Lp != nullptr;
+      });
+      if (!Lp) return;   // stop, nothing left to take
+      Lp->claimed = true;
     }
+    pipe_lane &L = *Lp;
     (void)finish_batch(q, L);   // a failure is sticky in q->failed; the lane is released either way
     {
-      // records leave in batch order: wait for the batches before this one (they are on the other lanes)
       std::unique_lock<std::mutex> lk(q->m);
       q->cv_turn.wait(lk, [&]() { return q->emit_seq == L.seq; });
       for (const uwspr_decode &d : L.recs) q->done.push_back(d);
       q->emit_seq++;
-      L.launched = false;
+      L.launched = false; L.claimed = false;
       L.busy = false;
     }
     q->cv_turn.notify_all();
@@ -378,7 +399,9 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
   }
   if (q->o.host_threads <= 0) q->o.host_threads = host_cpu_share() > 3 ? host_cpu_share() - 2 : 1;
   q->pool = &host_pool::shared();   // the process-wide pool; this pipe's jobs use host_threads of it
-  for (int k = 0; k < (int)q->lanes.size(); k++) q->coords.emplace_back(coordinator, q, k);
+  int ncoords = (int)q->lanes.size();
+  if (const char *e = getenv("UWSPR_PIPE_COORDS")) { if (atoi(e) >= 1 && atoi(e) < ncoords) ncoords = atoi(e); }
+  for (int k = 0; k < ncoords; k++) q->coords.emplace_back(coordinator, q);
   return UWSPR_OK;
 }
 
