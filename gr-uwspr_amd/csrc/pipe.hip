@@ -120,6 +120,7 @@ static int pfail(uwspr_pipe *q, int status, const char *fmt, ...) {
 // ---- coordinator: finishes the batches in launch order ------------------------------------------
 static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
   const int per = q->per, B = L.B, nrec = B * per;
+  L.recs.clear();   // (a failure below emits nothing for this batch)
   double t0 = now_s();
   PHIP(q, hipEventSynchronize(L.ev_done));
   double t1 = now_s();
@@ -196,7 +197,6 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
   }
   double t4 = now_s();
   int ncand = 0, ndec = 0;
-  L.recs.clear();
   {
     for (int b = 0; b < B; b++) {
       for (int j = 0; j < per; j++) {
