@@ -328,6 +328,60 @@ def test_schedule_without_lag_groups_is_identical(G, frames, vec, monkeypatch):
     assert (outs[0][:, 0]["symbols"] == vec["demod_symbols"]).all()
 
 
+def test_schedule_forms_on_random_candidates(G, oracle, monkeypatch):
+    """Hand-made candidates that the packed / table kernels must not trip over: frames with 0..5 candidates (dead
+    slots between live ones), shifts from before the frame start to the last one whose windows fit, drifting linear
+    models (no phasor table: the recurrence kernels take them) next to drift-free and straight-line ones in the same
+    workgroups.  Fused kernel, staged form and staged form with the round-3 kernels switched off: identical bytes;
+    a sample of the records against the oracle."""
+    rng = np.random.default_rng(2024)
+    frames = np.concatenate([G.synth.make_frames(4, seed=606, snr_db=-17.0),
+                             (0.5 * rng.standard_normal((2, 45000, 2))).astype(np.float32)])
+    per = 5
+    cands = []
+    for b in range(6):
+        n = [5, 0, 3, 1, 0, 4][b]
+        c = np.zeros(n, oracle.CAND_DTYPE)
+        for j in range(n):
+            c[j]["freq"] = np.float32(rng.uniform(-8, 8))
+            c[j]["shift"] = int(rng.choice([-50, 0, 200, 375, 1500, 3300, 3600]))
+            c[j]["sync"] = 0.3
+            if rng.random() < 0.5:
+                c[j]["m_type"] = 1
+                c[j]["V1"] = float(rng.integers(-2, 3)); c[j]["V2"] = float(rng.integers(-2, 3))
+                c[j]["p1"] = 0; c[j]["p2"] = int(rng.choice([50, 250, 450, 650, 850]))
+            else:
+                c[j]["m_type"] = 0
+                drift = np.float32(rng.choice([0.0, 0.0, 0.5, -1.5]))
+                c[j] = np.frombuffer(c[j].tobytes()[:24] + drift.tobytes() + c[j].tobytes()[28:], oracle.CAND_DTYPE)[0]
+        cands.append(c)
+    cands[0][0]["freq"] = frames.dtype.type(0.0)       # one candidate on the generated signal's grid
+    outs = {}
+    for name, env in (("fused", {"UWSPR_SCHED_FUSED": "1"}),
+                      ("staged", {"UWSPR_SCHED_FUSED": "0"}),
+                      ("staged-r2", {"UWSPR_SCHED_FUSED": "0", "UWSPR_K4_LAG0": "0", "UWSPR_K4_FPACK": "0", "UWSPR_K4_PTAB": "0"}),
+                      ("staged-mixed", {"UWSPR_SCHED_FUSED": "0", "UWSPR_K4_LAG0": "1", "UWSPR_K4_FPACK": "0", "UWSPR_K4_RING": "0"})):
+        for k in ("UWSPR_SCHED_FUSED", "UWSPR_K4_LAG0", "UWSPR_K4_FPACK", "UWSPR_K4_PTAB", "UWSPR_K4_RING"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = G.Context()
+        try:
+            outs[name] = c.demod_batch(frames, cands, max_per_frame=per)
+        finally:
+            c.close()
+    for name in ("staged", "staged-r2", "staged-mixed"):
+        assert outs[name].tobytes() == outs["fused"].tobytes(), name
+    for b, j in ((0, 0), (0, 3), (2, 1), (3, 0), (5, 2)):
+        d = oracle.demod_candidate(cands[b][j], 1500, frames[b])
+        o = outs["staged"][b, j]
+        assert int(o["shift1"]) == d["shift1"] and int(o["worth_a_try"]) == d["worth_a_try"], (b, j)
+        for k in ("f1", "drift1", "sync1"):
+            assert np.float32(o[k]).tobytes() == np.float32(d[k]).tobytes(), (b, j, k)
+        if d["worth_a_try"]:
+            assert (o["symbols"] == d["symbols"]).all(), (b, j)
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_whole_pipeline_on_fresh_and_growing_contexts(G, frames, monkeypatch, fused):
     """uwspr_pipeline_batch (candidates straight from the context's own FDR: the stage-0 lag-group launch is then
