@@ -255,13 +255,23 @@ def main():
                     uid_t.copy_(torch.frombuffer(bytearray(G.Context.dist_unique_id()), dtype=torch.uint8))
                 dist.broadcast(uid_t, src=0)
                 gctx.dist_init(rank, world, bytes(uid_t.cpu().numpy().tobytes()))
+                # a first, small gather under the same watchdog: every rank sends 4 KB of its rank number
+                probe = torch.full((4096,), rank, dtype=torch.uint8, device=dev)
+                got = torch.zeros((world, 4096), dtype=torch.uint8, device=dev) if rank == 0 else None
+                torch.cuda.synchronize()
+                gctx.dist_gather(probe, got, root=0)
+                gctx.synchronize()
+                if rank == 0:
+                    want = torch.arange(world, dtype=torch.uint8, device=dev)[:, None].expand(world, 4096)
+                    if not torch.equal(got, want):
+                        raise RuntimeError("probe gather returned wrong bytes")
                 state["ok"] = True
             except Exception as e:                       # noqa: BLE001 -- any failure means: use torch's gather
                 state["err"] = repr(e)
 
         th = threading.Thread(target=_init, daemon=True)
         th.start()
-        th.join(120.0)                                   # a communicator that does not come up in 2 min is given up
+        th.join(120.0)                   # a communicator (+ its first gather) not up in 2 min is given up
         okt = torch.tensor([1 if (state["ok"] and not th.is_alive()) else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if int(okt.item()) == 1:
