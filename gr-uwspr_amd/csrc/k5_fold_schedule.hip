@@ -40,6 +40,7 @@ __global__ __launch_bounds__(64) void k5_fold(const dev_hyp *__restrict__ hyps,
                                               float symfac, float *__restrict__ sync,
                                               uint8_t *__restrict__ symbols,
                                               const float4 *__restrict__ pwin, int per_slot) {
+  UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   __shared__ __align__(16) float4 tile[64 * K5L_CH];          // [hyp][9]
   __shared__ __align__(16) uint8_t bytes[64 * UWSPR_NSYM];    // [hyp][162]
   __shared__ int rowoff[64];                                  // float4 index of each hypothesis' row 0, or -1: in pwin
@@ -303,6 +304,7 @@ template <bool SOFT>
 __global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave(
     const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p, int H, float symfac,
     float *__restrict__ sync, uint8_t *__restrict__ symbols, const float4 *__restrict__ pwin, int per_slot) {
+  UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   __shared__ k5_wave_lds L[K5W_WAVES];
   __shared__ k5_wave_lds_soft Q[SOFT ? K5W_WAVES : 1];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -463,6 +465,7 @@ __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
                              const int32_t *__restrict__ npk, int cand_stride, int B,
                              int per_frame, float cf, cand_state *__restrict__ state,
                              dev_hyp *__restrict__ hyps, dev_grp *__restrict__ grps, float2 *__restrict__ ptab) {
+  UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   // one wavefront per slot: every lane derives the same state (lane 0 writes it), lanes 0..3 build table set A
   const int slot = blockIdx.x;
   if (slot >= B * per_frame) return;
@@ -671,6 +674,7 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
                              dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
                              uwspr_candidate *__restrict__ cent, int32_t *__restrict__ cframe, int nslots,
                              int reuse, int njig, float4 *__restrict__ pwin, float2 *__restrict__ ptab) {
+  UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   constexpr int NIN = STAGE == 3 ? 2 : 5;
   __shared__ k5_wave_lds L[LDS ? (ONEWAVE ? 1 : NIN) : 1];
   __shared__ float sy[NIN];
@@ -712,6 +716,7 @@ __global__ void k_sched_finish(const cand_state *__restrict__ state,
                                const dev_hyp *__restrict__ h5, const float *__restrict__ sync5,
                                const uint8_t *__restrict__ sym5, uwspr_demod_out *__restrict__ out,
                                int nslots, int njig) {
+  UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   const int slot = blockIdx.x;
   if (slot >= nslots) return;
   const cand_state st = state[slot];
@@ -750,6 +755,7 @@ __global__ void k_pack_slabs(const uwspr_candidate *__restrict__ cands,
                              const int32_t *__restrict__ npk, int maxfreqs,
                              const uwspr_demod_out *__restrict__ dout, int per_frame, int K,
                              uint8_t *__restrict__ slab, int B) {
+  UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   const int b = blockIdx.x;
   if (b >= B) return;
   const int slab_bytes = 16 + K * 48 + 16;
@@ -837,6 +843,7 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots, int njig) {
 // known hypothesis, copied here when it was correlated (no stage-4 winner to repeat)
 __global__ void k_keep_try0(const dev_hyp *__restrict__ h5, const float4 *__restrict__ p, float4 *__restrict__ pwin,
                             int njig, int nslots) {
+  UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   const int slot = blockIdx.x;
   if (slot >= nslots || h5[(size_t)slot * njig].frame < 0) return;   // known (<= -2) or dead (-1): nothing to copy
   for (int e = threadIdx.x; e < UWSPR_NSYM; e += blockDim.x)

@@ -41,6 +41,17 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nwg) {
 #endif
 }
 
+// Instruction-issue priority of the short kernels' wavefronts (s_setprio, 0..3).  Under several streams the kernels
+// of different lanes share the SIMDs and the arbiter serves higher priority first, then age: a fold or a schedule
+// transition that takes 6 us alone took 40-65 us beside the other lanes' correlation launches, and every lane's chain
+// waits on five of them per step.  With priority 3 in the K5 family (folds, schedule init / transitions / finish,
+// slab packing) `value` rises 2 % (profiles/r03_ab_experiments.txt); raising K1..K3 or the S0..S4 correlation
+// launches above the jiggered-shift ring as well adds nothing.  -DUWSPR_SMALL_PRIO=0 restores the default priority.
+#ifndef UWSPR_SMALL_PRIO
+#define UWSPR_SMALL_PRIO 3
+#endif
+#define UWSPR_SET_PRIO(level) do { if ((level) > 0) __builtin_amdgcn_s_setprio(level); } while (0)
+
 // fine-grid hypothesis as the kernels consume it (24 B)
 struct dev_hyp {
   int32_t frame;   // <0: skip

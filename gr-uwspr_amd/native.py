@@ -6,6 +6,7 @@ path behind it: if the library cannot be built or loaded, or no gfx950 device
 is present, calls raise UwsprError.
 """
 import ctypes as C
+import hashlib
 import os
 import shutil
 import subprocess
@@ -18,8 +19,10 @@ LIBDIR = os.path.join(_HERE, "lib")
 # Experiment builds (UWSPR_EXTRA_HIPFLAGS set: -DK6_EXP=..., stamps, flag A/Bs) go to their OWN
 # library file, so the product libuwspr_hip.so is never replaced by a build whose results may be
 # invalid; with the variable unset the product library is (re)built from the default flags.
-_EXTRA = os.environ.get("UWSPR_EXTRA_HIPFLAGS", "").split()
-LIBPATH = os.path.join(LIBDIR, "libuwspr_hip_exp.so" if _EXTRA else "libuwspr_hip.so")
+_EXTRA = os.environ.get("UWSPR_EXTRA_HIPFLAGS", "").replace(",", " ").split()   # (commas: for shell A/B scripts)
+# (one file per flag set, so that interleaved A/B runs do not rebuild each other's library)
+_EXTRA_TAG = hashlib.sha256(" ".join(_EXTRA).encode()).hexdigest()[:8] if _EXTRA else ""
+LIBPATH = os.path.join(LIBDIR, "libuwspr_hip_exp_%s.so" % _EXTRA_TAG if _EXTRA else "libuwspr_hip.so")
 HOSTLIB = os.path.join(LIBDIR, "libuwspr_blocks.so")
 
 SOURCES = ["uwspr_api.hip", "k0_frontend.hip", "k1_spectrogram.hip", "k2_spectrum.hip", "k3_coarse.hip",
