@@ -115,6 +115,15 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
   const bool mineA = pr < sb;
   const int own_i = mineA ? iA0 + pr : pr - sb;
   const bool own_ok = mineA ? okA : (okB && (g0 + pr) < total);
+  // nothing live in this wavefront (a noise-only stream leaves most candidates' later stages dead): zeros, done
+  if (!okA && !(okB && sb < PPW)) {   // wave-uniform
+    if (g0 + pr < total) {
+      float *out = p_out + (g0 + pr) * 4 + tone0;
+#pragma unroll
+      for (int j = 0; j < T; j++) out[j] = 0.0f;
+    }
+    return;
+  }
   const int own_nb = (mineA ? A.lag : Bh.lag) + 256 * own_i;  // first sample index
   const bool interior = __all((own_nb > 0) && (own_nb + 255 < np));
 
@@ -559,6 +568,12 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   const bool knownA = !okA || (A.nvalid & 0x100) != 0, knownB = !okB || (Bg.nvalid & 0x100) != 0;
   // (NL == 6, the jiggered shifts: the middle group's lag slot 2 is try 0, known when it repeats the stage-4 winner)
   const bool skip_mid = (NL == 5 || NL == 6) && knownA && (knownB || sb >= PPW);
+  // (NL == 6: the last of a slot's three jiggered-shift groups holds five tries -- its lag slot 5 belongs to nobody and is
+  // left out when that holds for every live group of the wave)
+#ifndef UWSPR_SKIP_LAST
+#define UWSPR_SKIP_LAST 1
+#endif
+  const bool skip_last = UWSPR_SKIP_LAST && NL == 6 && !skip_mid && (okA || liveB) && (!okA || nvA <= 5) && (!liveB || nvB <= 5);
   // first lag of the two groups; skipped groups point at safe samples
   const int l0A = okA ? A.lag[0] : 1 - 256 * iA0;
   const int l0B = okB ? Bg.lag[0] : 1;
@@ -567,6 +582,16 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
   const int tone = lane & 3;
   const bool mineA = pr < sb;
   const int own_i = mineA ? iA0 + pr : pr - sb;
+  // nothing live in this wavefront (candidates that were not worth a try leave their S3..S5 groups dead: on a
+  // noise-only stream that is most of them): zeros for the dead groups' hypotheses, done
+  if (!okA && !liveB) {   // wave-uniform
+    if (g0 + pr < total) {
+      const dev_grp &gy = mineA ? A : Bg;
+      for (int l = 0; l < (gy.nvalid & 0xff) && l < NL; l++)
+        p_out[((long long)(gy.hyp_base + (int)((gy.hmap >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
+    }
+    return;
+  }
   const int own_nb = (mineA ? l0A : l0B) + 256 * own_i;
   const bool interior = __all((own_nb > 0) && (own_nb + 255 + 16 * Q < np)  /* the loader fetches whole slots */);
 
@@ -671,7 +696,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
 
   int wpos = 0;  // ring position that slot c + Q + 1 will overwrite (= position of slot c)
   auto walk = [&](auto skip_tag, auto tab_tag) {
-    constexpr bool SKIP = decltype(skip_tag)::value;   // leave lag slot 2 out
+    constexpr int SKIPL = decltype(skip_tag)::value;   // lag slot left out: 2 (known), NL - 1 (unused), -1 (none)
     constexpr bool TAB = decltype(tab_tag)::value;     // phasors from the table slice, no recurrence
     for (int ch = 0; ch < 16; ch++) {
       // in flight during the chunk's arithmetic (the last chunk re-fetches the last slot: no
@@ -688,7 +713,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
       float4 vc[NL], vn[NL];
 #pragma unroll
       for (int l = 0; l < NL; l++) {
-        if (SKIP && l == 2) { vc[l] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); vn[l] = vc[l]; continue; }
+        if (l == SKIPL) { vc[l] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); vn[l] = vc[l]; continue; }
         vc[l] = *reinterpret_cast<const float4 *>(&lds[sa[(STEP * l) >> 4] + 2 * ((STEP * l) & 15)]);
         vn[l] = vc[l];
       }
@@ -697,7 +722,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
         if (k < 14) {
 #pragma unroll
           for (int l = 0; l < NL; l++) {
-            if (SKIP && l == 2) continue;
+            if (l == SKIPL) continue;
             const int o = k + 2 + STEP * l;
             vn[l] = *reinterpret_cast<const float4 *>(&lds[sa[o >> 4] + 2 * (o & 15)]);
           }
@@ -711,7 +736,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
           const float pc = TAB ? (half ? ph.z : ph.x) : c, psn = TAB ? (half ? ph.w : ph.y) : s;
 #pragma unroll
           for (int l = 0; l < NL; l++) {
-            if (SKIP && l == 2) continue;
+            if (l == SKIPL) continue;
             const float xx = half ? vc[l].z : vc[l].x, xy = half ? vc[l].w : vc[l].y;
             k4_mac<FAST>(inp[l], quad[l], xx, xy, pc, psn);   // cc:206-207
           }
@@ -731,8 +756,18 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
       sa[M - 1] = first;
     }
   };
-  if (use_tab) { if (skip_mid) walk(std::true_type{}, std::true_type{}); else walk(std::false_type{}, std::true_type{}); }
-  else { if (skip_mid) walk(std::true_type{}, std::false_type{}); else walk(std::false_type{}, std::false_type{}); }
+  using sk_none = std::integral_constant<int, -1>;
+  using sk_mid = std::integral_constant<int, 2>;
+  using sk_last = std::integral_constant<int, NL == 6 ? NL - 1 : -1>;
+  if (use_tab) {
+    if (skip_mid) walk(sk_mid{}, std::true_type{});
+    else if (skip_last) walk(sk_last{}, std::true_type{});
+    else walk(sk_none{}, std::true_type{});
+  } else {
+    if (skip_mid) walk(sk_mid{}, std::false_type{});
+    else if (skip_last) walk(sk_last{}, std::false_type{});
+    else walk(sk_none{}, std::false_type{});
+  }
 
   if (g0 + pr < total) {
     const int nv = mineA ? nvA : nvB;
@@ -1188,6 +1223,14 @@ __global__ __launch_bounds__(256) void k4_fpack(
   const int own_slot = mineA ? slotA : slotB;
   const bool own_live = mineA ? liveA : liveB;
   const bool valid = (g0 + row < total) && (mineA || hasB);
+  // nothing live in this workgroup (slots that were not worth a try): zeros, done (workgroup-uniform, before any barrier)
+  if (!liveA && !liveB) {
+    if (valid) {
+#pragma unroll
+      for (int q = 0; q < NF; q++) p_out[(((long long)own_slot * NF + q) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
+    }
+    return;
+  }
   const dev_hyp &ho = mineA ? hA : hB;
   const float delta = ((float)tone - 1.5f) * 1.46484375f;                    // cc:148
 
