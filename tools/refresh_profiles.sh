@@ -5,7 +5,7 @@
 # plus profiles/<tag>_valu_lds_by_kernel.txt (from gpurun_out/pmc_all.txt) and <tag>_overlap_3streams.txt (gpurun_out/overlap3.txt).
 TAG=${1:-r03}
 export TMPDIR=/tmp
-rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_all gpurun_out/overlap3
+rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_all gpurun_out/overlap3   # (also remove them HERE before the call: the merge-back adds to what is there)
 bash tools/run_profiles.sh $TAG > gpurun_out/run_profiles.log 2>&1
 echo "profiles done"
 bash tools/pmc_all.sh > gpurun_out/pmc_all.txt 2>&1
