@@ -203,8 +203,8 @@ def main():
     # the end-to-end pipes (their contexts, lane streams and copy streams) are created here as well, for
     # the same reason; they idle until their legs run
     host_legs = rank == 0 and world == 1 and not args.no_host_legs and args.total_frames <= 0
-    pipes_e2e = {f: G.Pipe(batch_frames=B, max_per_frame=1, lanes=3, sched=f) for f in ("fused", "staged")} if host_legs else {}
-    pipe_st = G.Pipe(hop=3375, batch_frames=B, max_per_frame=1, lanes=3) if host_legs else None
+    pipes_e2e = {f: G.Pipe(batch_frames=B, max_per_frame=1, lanes=0, sched=f) for f in ("fused", "staged")} if host_legs else {}
+    pipe_st = G.Pipe(hop=3375, batch_frames=B, max_per_frame=1, lanes=0) if host_legs else None
 
     def make_lanes(ns, fused):
         os.environ["UWSPR_SCHED_FUSED"] = "1" if fused else "0"
@@ -515,7 +515,7 @@ def main():
         best = max(by_form, key=lambda f: by_form[f]["frames_per_s"])
         e2e = dict(by_form[best])
         e2e.update({"sched": best, "by_sched": {f: v["frames_per_s"] for f, v in by_form.items()}, "repeats": REP,
-                    "steps_per_repeat": KS, "frames_per_step": B, "lanes": 3, "host_threads": max(1, G.host_threads() - 2),
+                    "steps_per_repeat": KS, "frames_per_step": B, "lanes": "library default: 3 streams + 6 spare lanes (opened only under long host tails)", "host_threads": max(1, G.host_threads() - 2),
                     "what": "uwspr_pipe_submit_device: frames resident in HBM (the same rotating batches as `value`), "
                             "FDR + lazy S0..S5 on 3 lanes, records to the host, Fano for every frame on the persistent "
                             "host pool, resume + Fano for what try 0 did not decode, messages collected in frame order"})

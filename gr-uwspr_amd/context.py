@@ -506,7 +506,7 @@ class Pipe:
     decode).  Results are DECODE_DTYPE records in frame order."""
 
     def __init__(self, fs=375, fl=45000, spb=256, maxdrift=0, maxfreqs=200, halfbandwidth=10, cf=1500,
-                 threshold=10, device=0, hop=3375, batch_frames=256, max_per_frame=1, lanes=3,
+                 threshold=10, device=0, hop=3375, batch_frames=256, max_per_frame=1, lanes=0,
                  host_threads=0, eager=False, sched=None):
         self.L = N.lib()
         self.h = C.c_void_p()

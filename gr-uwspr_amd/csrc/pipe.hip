@@ -35,6 +35,8 @@ using namespace uwspr;
 
 namespace {
 
+constexpr int kPipeStreams = 3;   // HIP streams the lanes share (see uwspr_pipe_open)
+
 struct pipe_lane {
   uwspr_ctx *ctx = nullptr;
   hipStream_t stream = nullptr;
@@ -45,6 +47,7 @@ struct pipe_lane {
   bool busy = false;       // taken by the producer, until its records have been emitted
   bool launched = false;   // its GPU work is enqueued: a coordinator may pick it up
   bool claimed = false;    // a coordinator has
+  double host_since = 0.0; // > 0: its first GPU pass is complete and it has been in its host tail since then (now_s())
   int64_t seq = 0;         // batch number (emission order)
   std::vector<uwspr_decode> recs;   // the batch's records, built by the coordinator, emitted in batch order
   int B = 0, stride = 0;
@@ -124,6 +127,10 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
   double t0 = now_s();
   PHIP(q, hipEventSynchronize(L.ev_done));
   double t1 = now_s();
+  {
+    std::lock_guard<std::mutex> lk(q->m);
+    L.host_since = t1;   // the host tail of this batch starts: the producer may open a spare lane if it lasts (take_lane)
+  }
   auto valid = [&](int i) { const int b = i / per, j = i - b * per; return j < L.h_npk[b] && j < q->maxfreqs; };
   // cc:457-490 on what the first pass produced (try 0 alone in the lazy flow)
   std::atomic<long long> calls(0), fails(0);
@@ -254,7 +261,7 @@ static void coordinator(uwspr_pipe *q) {
       q->cv_turn.wait(lk, [&]() { return q->emit_seq == L.seq; });
       for (const uwspr_decode &d : L.recs) q->done.push_back(d);
       q->emit_seq++;
-      L.launched = false; L.claimed = false;
+      L.launched = false; L.claimed = false; L.host_since = 0.0;
       L.busy = false;
     }
     q->cv_turn.notify_all();
@@ -264,13 +271,35 @@ static void coordinator(uwspr_pipe *q) {
 }
 
 // ---- producer side --------------------------------------------------------------------------------
+// The first kPipeStreams lanes (one per HIP stream) take the batches in turn: that is what a GPU-bound stream wants
+// (more batches in flight only cost it cache and 6 % of its rate).  The lanes beyond them are SPARES for a stream whose
+// host tail is the bottleneck -- Fano time-outs, 4 ms of a core each: a spare is opened only while every base lane is busy
+// and one of them has been in its host tail (first GPU pass complete) for longer than kSpareAfter.
+constexpr double kSpareAfter = 1.0e-3;   // seconds
 static pipe_lane *take_lane(uwspr_pipe *q) {
   std::unique_lock<std::mutex> lk(q->m);
-  pipe_lane &L = q->lanes[q->next_lane];
-  q->cv_lane.wait(lk, [&]() { return !L.busy; });
-  L.busy = true;
-  q->next_lane = (q->next_lane + 1) % (int)q->lanes.size();
-  return &L;
+  const int n = (int)q->lanes.size(), base = n < kPipeStreams ? n : kPipeStreams;
+  pipe_lane *pick = nullptr;
+  for (;;) {
+    for (int k = 0; k < base && !pick; k++) {
+      const int idx = (q->next_lane + k) % base;
+      if (!q->lanes[idx].busy) { pick = &q->lanes[idx]; q->next_lane = (idx + 1) % base; }
+    }
+    if (pick) break;
+    if (n > base) {
+      const double now = now_s();
+      bool slow_tail = false;
+      for (int k = 0; k < base; k++) slow_tail |= q->lanes[k].host_since > 0.0 && now - q->lanes[k].host_since > kSpareAfter;
+      if (slow_tail)
+        for (int k = base; k < n && !pick; k++) if (!q->lanes[k].busy) pick = &q->lanes[k];
+      if (pick) break;
+      q->cv_lane.wait_for(lk, std::chrono::microseconds(500));   // (a host tail grows old without anybody notifying)
+    } else {
+      q->cv_lane.wait(lk);
+    }
+  }
+  pick->busy = true;
+  return pick;
 }
 
 static int launch(uwspr_pipe *q, pipe_lane &L, const float *frames, int B, int stride, int64_t pos0, int ringbuf) {
@@ -330,8 +359,10 @@ extern "C" void uwspr_pipe_close(uwspr_pipe *q) {
   q->cv_work.notify_all();
   for (auto &t : q->coords) if (t.joinable()) t.join();
   (void)hipSetDevice(q->device);
+  for (auto &L : q->lanes) if (L.stream) (void)hipStreamSynchronize(L.stream);
+  for (auto &L : q->lanes)   // lanes beyond the stream count ran on another lane's stream: back to their own before any is destroyed
+    if (L.ctx && L.stream != L.ctx->own_stream) { (void)uwspr_set_stream(L.ctx, nullptr); L.stream = L.ctx->own_stream; }
   for (auto &L : q->lanes) {
-    if (L.stream) (void)hipStreamSynchronize(L.stream);
     void *dev[] = {L.d_cands, L.d_npk, L.d_out, L.d_need};
     for (void *b : dev) if (b) (void)hipFree(b);
     void *host[] = {L.h_cands, L.h_npk, L.h_out, L.h_need};
@@ -359,8 +390,9 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
   *out = q;   // handed back even on failure so uwspr_pipe_last_error() can be read
   if (q->o.batch_frames <= 0) q->o.batch_frames = 256;
   if (q->o.max_per_frame <= 0) q->o.max_per_frame = 1;
-  if (q->o.lanes <= 0) q->o.lanes = 3;
-  if (q->o.lanes > 8) q->o.lanes = 8;
+  if (q->o.lanes <= 0) q->o.lanes = 9;   // three streams + six spares (take_lane)
+  if (const char *e = getenv("UWSPR_PIPE_LANES")) { if (atoi(e) > 0) q->o.lanes = atoi(e); }   // (probes)
+  if (q->o.lanes > 12) q->o.lanes = 12;
   if (q->o.hop <= 0) q->o.hop = p->fl;
   if (q->o.hop > p->fl) return pfail(q, UWSPR_ERR_ARG, "hop=%d > fl=%d", q->o.hop, p->fl);
   q->per = q->o.max_per_frame < p->maxfreqs ? q->o.max_per_frame : p->maxfreqs;
@@ -370,12 +402,23 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
     const int rc = uwspr_ctx_create(p, device, &L.ctx);
     if (rc) return pfail(q, rc, "uwspr_ctx_create: %s", L.ctx ? uwspr_last_error(L.ctx) : uwspr_status_string(rc));
     L.stream = L.ctx->own_stream;
+    // At most kPipeStreams HIP streams: lane k >= kPipeStreams launches on the stream of lane k % kPipeStreams (a
+    // fourth stream shares a hardware queue with another and the GPU-bound rate drops: 4 / 6 lanes 734 / 833 k
+    // against 861 k for 3, round-3 probe).  The extra lanes are batches in flight on the HOST side -- their own
+    // buffers and coordinator -- which is what a stream with many Fano time-outs needs (busy stream: 39 k frames/s
+    // with 3 lanes, 49 k with 6 on 3 streams).
+    const int lane_idx = (int)(&L - &q->lanes[0]);
+    if (lane_idx >= kPipeStreams) {
+      const int rcs = uwspr_set_stream(L.ctx, q->lanes[lane_idx % kPipeStreams].ctx->own_stream);
+      if (rcs) return pfail(q, rcs, "uwspr_set_stream: %s", uwspr_last_error(L.ctx));
+      L.stream = q->lanes[lane_idx % kPipeStreams].ctx->own_stream;
+    }
     // schedule form: with three or more batches in flight the staged launches leave room for the other
     // lanes' kernels and win (861 k against 773 k decoded frames/s at 3 lanes); alone or in pairs the fused
     // kernel does (tools/pipe_lanes_probe.py).  UWSPR_SCHED_FUSED in the environment still decides when set.
     if (q->o.sched_form == 1) L.ctx->use_fused = true;
     else if (q->o.sched_form == 2) L.ctx->use_fused = false;
-    else if (!getenv("UWSPR_SCHED_FUSED")) L.ctx->use_fused = q->o.lanes < 3;
+    else if (!getenv("UWSPR_SCHED_FUSED")) L.ctx->use_fused = q->o.lanes < kPipeStreams;
     PHIP(q, hipMalloc((void **)&L.d_cands, (size_t)Bm * p->maxfreqs * sizeof(uwspr_candidate)));
     PHIP(q, hipMalloc((void **)&L.d_npk, (size_t)Bm * sizeof(int32_t)));
     PHIP(q, hipMalloc((void **)&L.d_out, (size_t)Bm * per * sizeof(uwspr_demod_out)));
