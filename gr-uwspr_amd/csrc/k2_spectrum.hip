@@ -15,7 +15,9 @@
 
 namespace uwspr {
 
-constexpr int K2_THREADS = 256;
+// 1024 threads: the frame's 60 KB tile comes into LDS with 16-byte loads, four per thread (with 256 threads and
+// 4-byte loads the copy alone was most of the kernel's 15 us); the later steps are strided loops over <= 512 items
+constexpr int K2_THREADS = 1024;
 constexpr int K2_MAXV = 512;  // >= band_w and >= finpb
 
 __global__ __launch_bounds__(K2_THREADS) void k2_spectrum(
@@ -23,7 +25,7 @@ __global__ __launch_bounds__(K2_THREADS) void k2_spectrum(
     float *__restrict__ smraw_g, float *__restrict__ smspec_g, float *__restrict__ noise_g,
     uwspr_candidate *__restrict__ cands, int32_t *__restrict__ npk_g, int stage_lds,
     int32_t *__restrict__ work_count, int32_t *__restrict__ work_list) {
-  extern __shared__ float ps_s[];  // [n][band_w] when stage_lds
+  extern __shared__ __align__(16) float ps_s[];  // [n][band_w] when stage_lds
   __shared__ float psavg[K2_MAXV];
   __shared__ float sm[K2_MAXV];
   __shared__ int flag[K2_MAXV];
@@ -41,7 +43,13 @@ __global__ __launch_bounds__(K2_THREADS) void k2_spectrum(
   // with all 256 threads (coalesced), then one thread per column adds it up.
   if (stage_lds) {
     const int tot = f.n * f.band_w;
-    for (int e = tid; e < tot; e += K2_THREADS) ps_s[e] = psb[e];
+    if ((tot & 3) == 0 && ((size_t)b * tot & 3) == 0) {   // 16-byte aligned frame tile (ps itself is)
+      const float4 *src = reinterpret_cast<const float4 *>(psb);
+      float4 *dst = reinterpret_cast<float4 *>(ps_s);
+      for (int e = tid; e < (tot >> 2); e += K2_THREADS) dst[e] = src[e];
+    } else {
+      for (int e = tid; e < tot; e += K2_THREADS) ps_s[e] = psb[e];
+    }
     __syncthreads();
     for (int col = tid; col < f.band_w; col += K2_THREADS) {
       float acc = 0.0f;
