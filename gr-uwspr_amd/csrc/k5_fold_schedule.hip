@@ -438,13 +438,22 @@ __device__ __forceinline__ void ptab_build(float2 *__restrict__ tabs, int nq, in
   sincos(kTwoPiDt5 * (double)(fp + delta), &sn, &cs);                                 // cc:188-189
   const float cd = (float)cs, sd = (float)sn;
   float c = 1.0f, sv = 0.0f;
-  float2 *t = tabs + (size_t)qi * kPtabFloat2 + tone * 256;
-#pragma unroll 8
-  for (int k = 0; k < 256; k++) {
-    t[k] = make_float2(c, sv);
-    const float nc = c * cd - sv * sd;   // cc:193-195
-    const float ns = c * sd + sv * cd;
-    c = nc; sv = ns;
+  float4 *t = reinterpret_cast<float4 *>(tabs + (size_t)qi * kPtabFloat2 + tone * 256);   // two steps per 16-byte store
+  for (int k = 0; k < 128; k += 4) {   // eight steps per trip: the recurrence runs ahead of its stores
+    float4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      v[j].x = c; v[j].y = sv;
+      float nc = c * cd - sv * sd;   // cc:193-195
+      float ns = c * sd + sv * cd;
+      c = nc; sv = ns;
+      v[j].z = c; v[j].w = sv;
+      nc = c * cd - sv * sd;
+      ns = c * sd + sv * cd;
+      c = nc; sv = ns;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) t[k + j] = v[j];
   }
 }
 
@@ -724,19 +733,34 @@ __global__ void k_sched_finish(const cand_state *__restrict__ state,
   const int tid = threadIdx.x;
   if (tid == 0) {
     o->f1 = st.f1; o->drift1 = st.drift1; o->sync1 = st.sync1; o->shift1 = st.shift1;
-    o->worth_a_try = st.worth; o->_pad[0] = 0; o->_pad[1] = 0;
+    o->worth_a_try = st.worth;
   }
   const bool on = st.frame >= 0 && st.worth;
   // lazy tries: the njig produced tries are packed njig per slot; the others read as zero (cc:457-490
   // would not have produced them either unless the earlier ones failed to decode)
+  // the slot's soft symbols through LDS: one coalesced read, then the per-try rms (162 serial terms each, cc:471-474)
+  // and the record's symbol block from there
+  static_assert((UWSPR_NJIG * UWSPR_NSYM) % 2 == 0 && UWSPR_NSYM % 2 == 0, "two-byte accesses below");
+  static_assert(offsetof(uwspr_demod_out, symbols) % 4 == 0 && sizeof(uwspr_demod_out) % 4 == 0 &&
+                offsetof(uwspr_demod_out, _pad) == offsetof(uwspr_demod_out, symbols) + UWSPR_NJIG * UWSPR_NSYM &&
+                sizeof(((uwspr_demod_out *)0)->_pad) == 2, "symbols + pad are written as 32-bit words below");
+  __shared__ __align__(4) uint8_t sy_s[UWSPR_NJIG * UWSPR_NSYM + 2];
+  const int nby = on ? njig * UWSPR_NSYM : 0;
+  {
+    const uint16_t *src = reinterpret_cast<const uint16_t *>(sym5 + (size_t)slot * njig * UWSPR_NSYM);   // (even offset)
+    uint16_t *dst = reinterpret_cast<uint16_t *>(sy_s);
+    for (int e = tid; e < (UWSPR_NJIG * UWSPR_NSYM + 2) / 2; e += blockDim.x) dst[e] = 2 * e < nby ? src[e] : (uint16_t)0;
+  }
+  __syncthreads();
   if (tid < UWSPR_NJIG) {
     const bool have = on && tid < njig;
     const size_t q = (size_t)slot * njig + tid;
     float rms = 0.0f;
     if (have) {
       float sq = 0.0f;
+#pragma unroll 6
       for (int i = 0; i < UWSPR_NSYM; i++) {
-        const float y = (float)((double)(float)sym5[q * UWSPR_NSYM + i] - 128.0);  // cc:471
+        const float y = (float)((double)(float)sy_s[tid * UWSPR_NSYM + i] - 128.0);  // cc:471
         sq += y * y;
       }
       rms = (float)sqrt((double)sq / 162.0);  // cc:474
@@ -745,8 +769,11 @@ __global__ void k_sched_finish(const cand_state *__restrict__ state,
     o->jig_rms[tid] = rms;
     o->jig_shift[tid] = have ? h5[q].lag : 0;
   }
-  for (int e = tid; e < UWSPR_NJIG * UWSPR_NSYM; e += blockDim.x)
-    (&o->symbols[0][0])[e] = (on && e < njig * UWSPR_NSYM) ? sym5[(size_t)slot * njig * UWSPR_NSYM + e] : (uint8_t)0;
+  {   // symbols + the two pad bytes (zero) as 689 words
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&o->symbols[0][0]);
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(sy_s);
+    for (int e = tid; e < (UWSPR_NJIG * UWSPR_NSYM + 2) / 4; e += blockDim.x) dst[e] = src[e];
+  }
 }
 
 // Per-frame slab for the multi-GPU gather: {npk, pad[3]} | candidate_t[K] |
