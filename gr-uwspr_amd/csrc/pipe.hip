@@ -274,8 +274,8 @@ static void coordinator(uwspr_pipe *q) {
 // The first kPipeStreams lanes (one per HIP stream) take the batches in turn: that is what a GPU-bound stream wants
 // (more batches in flight only cost it cache and 6 % of its rate).  The lanes beyond them are SPARES for a stream whose
 // host tail is the bottleneck -- Fano time-outs, 4 ms of a core each: a spare is opened only while every base lane is busy
-// and one of them has been in its host tail (first GPU pass complete) for longer than kSpareAfter.
-constexpr double kSpareAfter = 1.0e-3;   // seconds
+// and one of them has been in its host tail (first GPU pass complete) for longer than kSpareAfter (2.5 ms).
+constexpr double kSpareAfter = 2.5e-3;   // seconds (a Fano time-out is ~4 ms; the host tail of a batch that decodes at once ~0.3 ms)
 static pipe_lane *take_lane(uwspr_pipe *q) {
   std::unique_lock<std::mutex> lk(q->m);
   const int n = (int)q->lanes.size(), base = n < kPipeStreams ? n : kPipeStreams;

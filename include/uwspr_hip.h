@@ -348,7 +348,7 @@ typedef struct uwspr_pipe_opts {
   int32_t max_per_frame;  /* candidates refined per frame (cc:389 refines all npk; 1 = the strongest) */
   int32_t lanes;          /* most batches in flight, each with its own context (0: 9).  The first three have a HIP stream
                              each and take the batches in turn; the others share those streams and are spares, opened
-                             only while every one of the three is busy and a host tail (Fano time-outs) has lasted > 1 ms */
+                             only while every one of the three is busy and a host tail (Fano time-outs) has lasted > 2.5 ms */
   int32_t host_threads;   /* Fano threads (0: uwspr_host_threads() - 2, leaving the producer and the HIP runtime a core each) */
   int32_t eager;          /* 1: all 17 tries in the first pass, no resume (A/B against the lazy flow) */
   int32_t sched_form;     /* 0: staged launches from 3 lanes up, the fused kernel below (UWSPR_SCHED_FUSED overrides), 1: fused, 2: staged */
