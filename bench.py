@@ -227,11 +227,17 @@ def main():
     # slabs of every step of a timed region: ONE gather at its end (off the per-step path)
     slab_ring = torch.zeros((K, Bmax, D.SLAB_BYTES), dtype=torch.uint8, device=dev)
 
+    separate_pack = os.environ.get("UWSPR_BENCH_SEPARATE_PACK", "0") == "1"
+
     def step(lanes, i):
         ln = lanes[i % len(lanes)]
         with torch.cuda.stream(ln["stream"]):
+            if separate_pack:                                        # (A/B: the packing kernel as its own launch)
+                ln["ctx"].pipeline_batch_into(batches[i % nb], ln["cands"], ln["npk"], ln["out"], max_per_frame=1)
+                ln["ctx"].pack_slabs_into(B, D.SLAB_K, slab_ring[i % K])
+                return
+            ln["ctx"].pipeline_slabs(D.SLAB_K, slab_ring[i % K])     # this batch's slabs from the schedule's last kernel
             ln["ctx"].pipeline_batch_into(batches[i % nb], ln["cands"], ln["npk"], ln["out"], max_per_frame=1)
-            ln["ctx"].pack_slabs_into(B, D.SLAB_K, slab_ring[i % K])
 
     def barrier():
         torch.cuda.synchronize()

@@ -353,6 +353,11 @@ class Context:
                                               C.c_void_p(npk_t.data_ptr()),
                                               C.c_void_p(out_t.data_ptr())))
 
+    def pipeline_slabs(self, K, slab_t):
+        """The next pipeline_batch* call also writes its frames' gather slabs into slab_t (torch CUDA uint8
+        [B, 32+48K]); None cancels."""
+        self._chk(self.L.uwspr_pipeline_slabs(self.h, int(K), C.c_void_p(slab_t.data_ptr()) if slab_t is not None else None))
+
     def pack_slabs_into(self, B, K, slab_t):
         """Per-frame gather slabs of the last pipeline batch, written into a torch
         CUDA uint8 tensor [B, 32+48K] (or a numpy array for the host form)."""

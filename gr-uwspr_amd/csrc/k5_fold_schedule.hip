@@ -721,10 +721,15 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
 }
 
 // out[slot]: state + per-try sync / rms / shift / symbols (cc:465-475)
+// slab != null (uwspr_pipeline_slabs): the workgroup of a frame's top candidate also writes the frame's gather slab
+// (k_pack_slabs' layout) -- the tail of the slab is this slot's own (f1, drift1, sync1, shift1), nothing is read
+// from another workgroup's record
 __global__ void k_sched_finish(const cand_state *__restrict__ state,
                                const dev_hyp *__restrict__ h5, const float *__restrict__ sync5,
                                const uint8_t *__restrict__ sym5, uwspr_demod_out *__restrict__ out,
-                               int nslots, int njig) {
+                               int nslots, int njig, const uwspr_candidate *__restrict__ cands,
+                               const int32_t *__restrict__ npk, int maxfreqs, int per_frame, int K,
+                               uint8_t *__restrict__ slab) {
   UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   const int slot = blockIdx.x;
   if (slot >= nslots) return;
@@ -773,6 +778,23 @@ __global__ void k_sched_finish(const cand_state *__restrict__ state,
     uint32_t *dst = reinterpret_cast<uint32_t *>(&o->symbols[0][0]);
     const uint32_t *src = reinterpret_cast<const uint32_t *>(sy_s);
     for (int e = tid; e < (UWSPR_NJIG * UWSPR_NSYM + 2) / 4; e += blockDim.x) dst[e] = src[e];
+  }
+  if (slab != nullptr && slot % per_frame == 0) {
+    const int b = slot / per_frame;
+    const int slab_bytes = 16 + K * 48 + 16, words = slab_bytes / 4;
+    uint32_t *so = reinterpret_cast<uint32_t *>(slab + (size_t)b * slab_bytes);
+    const uint32_t *cw = reinterpret_cast<const uint32_t *>(cands + (size_t)b * maxfreqs);
+    const int n = npk[b];
+    for (int w = tid; w < words; w += blockDim.x) {
+      uint32_t v = 0;
+      if (w == 0) v = (uint32_t)n;
+      else if (w >= 4 && w < 4 + K * 12) { const int k = (w - 4) / 12; v = (k < n && k < maxfreqs) ? cw[w - 4] : 0u; }
+      else if (w >= 4 + K * 12) {
+        const int t = w - 4 - K * 12;
+        v = t == 0 ? __float_as_uint(st.f1) : t == 1 ? __float_as_uint(st.drift1) : t == 2 ? __float_as_uint(st.sync1) : (uint32_t)st.shift1;
+      }
+      so[w] = v;
+    }
   }
 }
 
@@ -886,8 +908,11 @@ void launch_sched_finish(uwspr_ctx *c, int nslots, int njig) {
   prof_scope ps(c, UWSPR_K_SCHED, nslots);
   // stage-5 hyps live in the half selected by (5 & 1) -> half1
   dev_hyp *h5 = c->d_hyps + (size_t)nslots * UWSPR_NJIG;
+  uint8_t *slab = c->cands_from_fdr ? c->next_slab : nullptr;   // (uwspr_pipeline_slabs: this batch's slabs in the same launch)
   hipLaunchKernelGGL(k_sched_finish, dim3(nslots), dim3(256), 0, c->stream, c->d_state, h5,
-                     c->d_sync, c->d_sym, c->cur_dout, nslots, njig);
+                     c->d_sync, c->d_sym, c->cur_dout, nslots, njig, c->cur_cands, c->cur_npk, c->fc.maxfreqs,
+                     c->sched_per_frame, c->next_slab_K, slab);
+  if (slab) c->next_slab_done = true;
 }
 
 }  // namespace uwspr

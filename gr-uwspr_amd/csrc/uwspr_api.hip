@@ -730,6 +730,7 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
                              const int32_t *dnpk, int cand_stride, int per_frame, uwspr_demod_out *user_out) {
   static const int hpc[6] = {5, 5, 2, 5, 5, UWSPR_NJIG};
   const size_t nslots = (size_t)B * per_frame;
+  c->sched_per_frame = per_frame;
   int rc;
   if ((rc = ensure(c, &c->d_state, &c->cap_state, nslots))) return rc;
   const int njig = c->ntries < UWSPR_NJIG ? c->ntries : UWSPR_NJIG;
@@ -860,6 +861,11 @@ extern "C" int uwspr_pipeline_batch(uwspr_ctx *c, const float *frames, int B, in
   if ((rc = run_schedule(c, d, B, c->cur_cands, c->cur_npk, c->fc.maxfreqs, max_per_frame,
                          dev ? out : nullptr))) return rc;
   c->last_per_frame = max_per_frame;
+  if (c->next_slab) {   // uwspr_pipeline_slabs: packed by the schedule's last kernel (staged form) or here
+    if (!c->next_slab_done) launch_pack_slabs(c, c->cur_cands, c->cur_npk, c->cur_dout, max_per_frame, c->next_slab_K, c->next_slab, B);
+    c->next_slab = nullptr; c->next_slab_done = false;
+    HIPCHK(c, hipGetLastError());
+  }
   if (c->cur_cands == c->d_cands &&
       (rc = copy_out(c, cands, c->d_cands, (size_t)B * c->fc.maxfreqs * sizeof(uwspr_candidate), where))) return rc;
   if (c->cur_npk == c->d_npk && (rc = copy_out(c, npk, c->d_npk, (size_t)B * sizeof(int32_t), where))) return rc;
@@ -1029,6 +1035,14 @@ extern "C" int uwspr_demod_resume(uwspr_ctx *c, const float *frames, int B, int 
     HIPCHK(c, hipMemcpyAsync(out, c->d_dout, nslots * sizeof(uwspr_demod_out), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_pipeline_slabs(uwspr_ctx *c, int K, void *slabs_device) {
+  int rc = ready(c);
+  if (rc) return rc;
+  if (slabs_device && (K < 1 || K > c->fc.maxfreqs)) return fail(c, UWSPR_ERR_ARG, "uwspr_pipeline_slabs: K=%d", K);
+  c->next_slab = (uint8_t *)slabs_device; c->next_slab_K = K; c->next_slab_done = false;
   return UWSPR_OK;
 }
 

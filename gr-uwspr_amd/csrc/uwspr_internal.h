@@ -172,6 +172,8 @@ struct uwspr_ctx {
   bool k4_lag0;          // S0 through the sample-major packed form for the slots that have a phasor table (UWSPR_K4_LAG0=0: k4_group)
   bool group_skip_tabled;   // set around the S0 k4_group launch that follows k4_lag0
   bool cands_from_fdr;   // the schedule call's candidates are this context's own FDR output (drift within +-maxdrift)
+  uint8_t *next_slab = nullptr; int next_slab_K = 0; bool next_slab_done = false;   // uwspr_pipeline_slabs (one shot)
+  int sched_per_frame = 1;   // candidate slots per frame of the schedule being launched
   bool k4_fpack;         // S1/S4 through the packed form (64 consecutive (slot, symbol) pairs per workgroup); UWSPR_K4_FPACK=0: k4_fstage
   bool k4f_onegen;       // k4_fstage: wavefront 0 generates all four tones' phasor tables (UWSPR_K4F_ONEGEN=0: each its own)
   bool k5_s5_lanes;      // UWSPR_K5_S5_LANES=1: the schedule's stage-5 fold through the lanes form (measured slower: 68 long wavefronts)

@@ -178,7 +178,7 @@ ABI_SYMBOLS = [
     "uwspr_device_alloc", "uwspr_device_free", "uwspr_host_alloc", "uwspr_host_free", "uwspr_fdr_batch",
     "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
     "uwspr_sync_sweep", "uwspr_sync_grid", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
-    "uwspr_pipeline_batch", "uwspr_set_tries", "uwspr_demod_resume", "uwspr_pack_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
+    "uwspr_pipeline_batch", "uwspr_set_tries", "uwspr_demod_resume", "uwspr_pack_slabs", "uwspr_pipeline_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
     "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_host_threads", "uwspr_decode_batch", "uwspr_unpack_message",
     "uwspr_c2_read",
     "uwspr_dist_unique_id", "uwspr_dist_init", "uwspr_dist_gather", "uwspr_dist_finalize",
@@ -249,6 +249,7 @@ def lib():
     L.uwspr_set_tries.argtypes = [vp, ip]
     L.uwspr_demod_resume.argtypes = [vp, vp, ip, ip, vp, ip, vp]
     L.uwspr_pack_slabs.argtypes = [vp, ip, ip, vp, ip]
+    L.uwspr_pipeline_slabs.argtypes = [vp, ip, vp]
     L.uwspr_prof_enable.argtypes = [vp, ip]
     L.uwspr_prof_read.argtypes = [vp, C.POINTER(Prof)]
     L.uwspr_prof_intervals.argtypes = [vp, ip, vp, vp, vp, ip, C.POINTER(C.c_int)]

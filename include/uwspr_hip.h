@@ -311,6 +311,10 @@ int uwspr_pipeline_batch(uwspr_ctx *ctx, const float *frames, int B, int where,
  *   | float f1, drift1, sync1; int32 shift1 of the frame's top candidate
  * = 32 + 48*K bytes per frame; slabs: [B][32+48K]. */
 int uwspr_pack_slabs(uwspr_ctx *ctx, int B, int K, void *slabs, int where);
+/* The same slabs without a launch of their own: the NEXT uwspr_pipeline_batch (one shot) also writes its frames' slabs
+ * to slabs_device ([B][32+48K] bytes in device memory) -- from the schedule's last kernel where the schedule form has
+ * one, else with the packing kernel behind it.  slabs_device = NULL cancels. */
+int uwspr_pipeline_slabs(uwspr_ctx *ctx, int K, void *slabs_device);
 
 /* ---- multi-GPU: the final gather over RCCL --------------------------------------- */
 /* One process per GPU, frames sharded round-robin (global frame b on rank b mod G), no data-path

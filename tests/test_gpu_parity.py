@@ -488,6 +488,28 @@ def test_gather_slabs_kernel_matches_reference_packing(ctx, G, frames):
     host = np.zeros((B, D.SLAB_BYTES), np.uint8)
     ctx.pack_slabs_into(B, D.SLAB_K, host)
     assert (host == got).all()
+    # uwspr_pipeline_slabs: the same bytes from the pipeline call itself, both schedule forms, eager and lazy
+    import os
+    for fused in ("1", "0"):
+        os.environ["UWSPR_SCHED_FUSED"] = fused
+        try:
+            c2 = G.Context()
+        finally:
+            del os.environ["UWSPR_SCHED_FUSED"]
+        try:
+            for tries in (17, 1):
+                c2.set_tries(tries)
+                slab2 = torch.zeros((B, D.SLAB_BYTES), dtype=torch.uint8, device="cuda")
+                c2.pipeline_slabs(D.SLAB_K, slab2)
+                c2.pipeline_batch_into(dev, cands_t, npk_t, out_t, max_per_frame=1)
+                c2.synchronize()
+                assert (slab2.cpu().numpy() == got).all(), (fused, tries)
+                slab3 = torch.zeros((B, D.SLAB_BYTES), dtype=torch.uint8, device="cuda")   # one shot: not written again
+                c2.pipeline_batch_into(dev, cands_t, npk_t, out_t, max_per_frame=1)
+                c2.synchronize()
+                assert not slab3.cpu().numpy().any()
+        finally:
+            c2.close()
 
 
 def test_full_size_properties_256_frames(ctx, G):
