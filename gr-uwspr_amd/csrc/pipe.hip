@@ -77,6 +77,7 @@ struct uwspr_pipe {
   int failed = 0;   // sticky status of the first failure (coordinator or producer)
 
   std::vector<pipe_lane> lanes;
+  double spare_after = 2.5e-3;   // seconds of host tail after which a spare lane may open (take_lane)
   int next_lane = 0;
   int64_t next_frame = 0;
 
@@ -276,6 +277,7 @@ static void coordinator(uwspr_pipe *q) {
 // host tail is the bottleneck -- Fano time-outs, 4 ms of a core each: a spare is opened only while every base lane is busy
 // and one of them has been in its host tail (first GPU pass complete) for longer than kSpareAfter (2.5 ms).
 constexpr double kSpareAfter = 2.5e-3;   // seconds (a Fano time-out is ~4 ms; the host tail of a batch that decodes at once ~0.3 ms)
+// (UWSPR_PIPE_SPARE_AFTER_US, read when a pipe is opened: tests open the spares at once with 0)
 static pipe_lane *take_lane(uwspr_pipe *q) {
   std::unique_lock<std::mutex> lk(q->m);
   const int n = (int)q->lanes.size(), base = n < kPipeStreams ? n : kPipeStreams;
@@ -289,7 +291,7 @@ static pipe_lane *take_lane(uwspr_pipe *q) {
     if (n > base) {
       const double now = now_s();
       bool slow_tail = false;
-      for (int k = 0; k < base; k++) slow_tail |= q->lanes[k].host_since > 0.0 && now - q->lanes[k].host_since > kSpareAfter;
+      for (int k = 0; k < base; k++) slow_tail |= q->lanes[k].host_since > 0.0 && now - q->lanes[k].host_since > q->spare_after;
       if (slow_tail)
         for (int k = base; k < n && !pick; k++) if (!q->lanes[k].busy) pick = &q->lanes[k];
       if (pick) break;
@@ -393,6 +395,7 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
   if (q->o.lanes <= 0) q->o.lanes = 9;   // three streams + six spares (take_lane)
   if (const char *e = getenv("UWSPR_PIPE_LANES")) { if (atoi(e) > 0) q->o.lanes = atoi(e); }   // (probes)
   if (q->o.lanes > 12) q->o.lanes = 12;
+  q->spare_after = getenv("UWSPR_PIPE_SPARE_AFTER_US") ? 1e-6 * atof(getenv("UWSPR_PIPE_SPARE_AFTER_US")) : kSpareAfter;
   if (q->o.hop <= 0) q->o.hop = p->fl;
   if (q->o.hop > p->fl) return pfail(q, UWSPR_ERR_ARG, "hop=%d > fl=%d", q->o.hop, p->fl);
   q->per = q->o.max_per_frame < p->maxfreqs ? q->o.max_per_frame : p->maxfreqs;
