@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak: whole pipeline (FDR + schedule) on many frames at mixed SNRs, GPU vs the CPU
-oracle, every candidate of every frame.  usage: soak_parity.py [nframes] [halfbandwidth] [maxdrift]"""
+oracle, every candidate of every frame.  usage: soak_parity.py [nframes] [halfbandwidth] [maxdrift] [seed base, default 5000]"""
 import os
 import sys
 import time
@@ -19,13 +19,14 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     hbw = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     maxdrift = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    seed0 = int(sys.argv[4]) if len(sys.argv) > 4 else 5000
     snrs = [-32.0, -28.0, -26.0, -24.0, -20.0, -10.0, None]
     parts = []
     for k, snr in enumerate(snrs):
         m = (n + len(snrs) - 1) // len(snrs)
-        fr = G.synth.make_frames(m, seed=5000 + 100 * k, snr_db=snr, halfbandwidth=hbw, maxdrift=float(maxdrift))
+        fr = G.synth.make_frames(m, seed=seed0 + 100 * k, snr_db=snr, halfbandwidth=hbw, maxdrift=float(maxdrift))
         if snr == -32.0:
-            fr[: m // 2] = (np.random.default_rng(9).standard_normal(fr[: m // 2].shape) * 0.5).astype(np.float32)
+            fr[: m // 2] = (np.random.default_rng(9 + seed0 - 5000).standard_normal(fr[: m // 2].shape) * 0.5).astype(np.float32)
         parts.append(fr)
     frames = np.concatenate(parts)[:n]
     per = 4
