@@ -35,7 +35,7 @@
 #include <algorithm>
 #include <type_traits>
 
-#include "uwspr_internal.h"
+#include "k4_common.h"
 
 #pragma clang fp contract(off)
 
@@ -43,43 +43,6 @@ namespace uwspr {
 
 constexpr int K4_WAVES = 4;
 constexpr int K4_ROWDW = 36;  // dwords per staged row: 16 samples x 8 B + 16 B pad (16-byte aligned rows)
-
-// 2*pi*dt with dt = (float)(1/375) -- cc:146,188: `2*M_PI*dt*(fp+delta[j])`
-constexpr double kTwoPiDt = 2.0 * 3.14159265358979323846 * (double)(float)(1.0 / 375.0);
-
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// The correlation step (cc:206-207) and the phasor rotation (cc:193-195).  FAST = false is the
-// reference's arithmetic: every product and every sum rounded on its own, left to right.  FAST = true
-// (UWSPR_FAST_SEARCH=1, stages S0..S4 only, never the soft symbols) contracts them into fused
-// multiply-adds: half the instructions, one rounding per product-sum -- metrics agree to ~1e-6 relative,
-// which may move an argmax at a near-tie (tools/fast_search_eval.py measures how often).
-template <bool FAST>
-__device__ __forceinline__ void k4_mac(float &inp, float &quad, float xx, float xy, float c, float s) {
-  if (FAST) {
-    inp = __builtin_fmaf(xy, s, __builtin_fmaf(xx, c, inp));
-    quad = __builtin_fmaf(xy, c, __builtin_fmaf(-xx, s, quad));
-  } else {
-    inp = (inp + xx * c) + xy * s;     // cc:206
-    quad = (quad - xx * s) + xy * c;   // cc:207
-  }
-}
-template <bool FAST>
-__device__ __forceinline__ void k4_rot(float &c, float &s, float cd, float sd) {
-  float nc, ns;
-  if (FAST) {
-    nc = __builtin_fmaf(c, cd, -(s * sd));
-    ns = __builtin_fmaf(c, sd, s * cd);
-  } else {
-    nc = c * cd - s * sd;              // cc:193-195
-    ns = c * sd + s * cd;
-  }
-  c = nc; s = ns;
-}
 
 template <int T, bool FAST = false>
 __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
@@ -1180,6 +1143,16 @@ void launch_tonecorr_lag0(uwspr_ctx *c, const float *frames, int B, const dev_gr
 // per phasor is k4_fstage's, i.e. the reference's sequence.  Fallbacks inside: a slot whose frequency depends on
 // the symbol (drifting linear model) puts the whole workgroup on per-lane recurrences; the known middle frequency
 // is left out only when every live slot of the workgroup has it marked.
+#ifdef K4F_STAMPS   // diagnostic build only (tools/k4f_stamps.py): where a k4_fpack wavefront's cycles go
+constexpr int K4F_STAMP_WAVES = 4096;
+__device__ unsigned long long g_k4f_stamps[K4F_STAMP_WAVES * 10];
+#define K4F_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define K4F_ACC(a, t1, t0) a += (t1) - (t0)
+#else
+#define K4F_T(v) do { } while (0)
+#define K4F_ACC(a, t1, t0) do { } while (0)
+#endif
+
 template <int NF, int CH, bool FAST = false>
 __global__ __launch_bounds__(256) void k4_fpack(
     const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_hyp *__restrict__ hyps,
@@ -1195,6 +1168,10 @@ __global__ __launch_bounds__(256) void k4_fpack(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int tone = __builtin_amdgcn_readfirstlane(tid >> 6);
+  #ifdef K4F_STAMPS
+  const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long st_bar1 = 0, st_gen = 0, st_bar2 = 0, st_ar = 0;
+#endif
   const long long total = (long long)nslots * UWSPR_NSYM;
   const long long g0 = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * ROWS;
   if (g0 >= total) return;  // workgroup-uniform
@@ -1299,7 +1276,9 @@ __global__ __launch_bounds__(256) void k4_fpack(
     auto walk = [&](auto skip_tag) {
       constexpr bool SKIP = decltype(skip_tag)::value;
       for (int ch = 0; ch < NCH; ch++) {
+        K4F_T(t0);
         __syncthreads();              // the previous chunk has been read by everyone
+        K4F_T(t1);
         store_chunk();
         if (gen) {
 #pragma unroll
@@ -1308,7 +1287,9 @@ __global__ __launch_bounds__(256) void k4_fpack(
             k4_rot<FAST>(cq, sq, cdq, sdq);         // cc:193-195
           }
         }
+        K4F_T(t2);
         __syncthreads();
+        K4F_T(t3);
         load_chunk(min(ch + 1, NCH - 1));  // in flight during the arithmetic (no branch around it)
 #pragma unroll
         for (int k = 0; k < CH; k += 2) {
@@ -1322,6 +1303,8 @@ __global__ __launch_bounds__(256) void k4_fpack(
             k4_mac<FAST>(inp[q], quad[q], x.z, x.w, ph.z, ph.w);      // step k + 1
           }
         }
+        K4F_T(t4);
+        K4F_ACC(st_bar1, t1, t0); K4F_ACC(st_gen, t2, t1); K4F_ACC(st_bar2, t3, t2); K4F_ACC(st_ar, t4, t3);
       }
     };
     if (skip_mid) walk(std::true_type{}); else walk(std::false_type{});
@@ -1359,6 +1342,18 @@ __global__ __launch_bounds__(256) void k4_fpack(
     }
   }
 
+#ifdef K4F_STAMPS
+  {
+    const unsigned gw = xcd_swizzle(blockIdx.x, gridDim.x) * 4 + tone;
+    if (lane == 0 && gw < (unsigned)K4F_STAMP_WAVES) {
+      unsigned long long *o = &g_k4f_stamps[(size_t)gw * 10];
+      o[0] = st_c0; o[1] = __builtin_amdgcn_s_memtime(); o[2] = st_r0; o[3] = __builtin_amdgcn_s_memrealtime();
+      o[4] = st_bar1; o[5] = st_gen; o[6] = st_bar2; o[7] = st_ar;
+      o[8] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+      o[9] = tabled ? 1 : 0;
+    }
+  }
+#endif
   if (valid) {
 #pragma unroll
     for (int q = 0; q < NF; q++) {
@@ -1664,5 +1659,12 @@ extern "C" int uwspr_debug_k4_stamps(unsigned long long *out, int nwaves) {
   if (nwaves > uwspr::K4_STAMP_WAVES) nwaves = uwspr::K4_STAMP_WAVES;
   hipDeviceSynchronize();
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(uwspr::g_k4_stamps), (size_t)nwaves * 32);
+}
+#endif
+#ifdef K4F_STAMPS
+extern "C" int uwspr_debug_k4f_stamps(unsigned long long *out, int nwaves) {
+  if (nwaves > uwspr::K4F_STAMP_WAVES) nwaves = uwspr::K4F_STAMP_WAVES;
+  hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(uwspr::g_k4f_stamps), (size_t)nwaves * 80);
 }
 #endif

@@ -457,25 +457,42 @@ __device__ __forceinline__ void ptab_build(float2 *__restrict__ tabs, int nq, in
   }
 }
 
-// table selector of a lag group (dev_grp::nvalid bits 16..23): 0 = none (every lane runs the recurrence),
-// else 1 + table index within the slot.  A table applies only if it was built and the group's frequency is
-// bit for bit the one it was built for.
-__device__ __forceinline__ int ptab_select(const cand_state &st, int set, float f0, float drift, bool on) {
-  if (!on) return 0;
-  if (st.m_type == UWSPR_LINEAR && drift != 0.0f) return 0;
-  if (set == 0) return (st.tabA_ok && __float_as_int(f0) == __float_as_int(st.tabA_f)) ? 1 : 0;
-  if (!st.tabB_ok) return 0;
+// Table selector: -1 = none (every lane runs the recurrence), else the table index within the slot.  A table applies
+// only if it was built and the frequency is bit for bit the one it was built for (set A: tabA_f + (q - 2) 0.25f,
+// set B: tabB_f + (q - 2) 0.05f -- the expressions ptab_build and the stage emitters use).
+__device__ __forceinline__ int ptab_index(const cand_state &st, int set, float f0, float drift, bool on) {
+  if (!on) return -1;
+  if (st.m_type == UWSPR_LINEAR && drift != 0.0f) return -1;
+  if (!(set == 0 ? st.tabA_ok : st.tabB_ok)) return -1;
+  const float fc = set == 0 ? st.tabA_f : st.tabB_f, step = set == 0 ? 0.25f : 0.05f;
   for (int q = 0; q < 5; q++)
-    if (__float_as_int(st.tabB_f + (float)(q - 2) * 0.05f) == __float_as_int(f0)) return 2 + q;
-  return 0;
+    if (__float_as_int(fc + (float)(q - 2) * step) == __float_as_int(f0)) return (set == 0 ? 0 : kPtabSetB) + q;
+  return -1;
+}
+// the same for a frequency stage (five hypotheses fc' + (q - 2) step): the set applies if the stage's centre is the
+// set's centre -- returns the set's first table or -1
+__device__ __forceinline__ int ptab_set(const cand_state &st, int set, float centre, float drift, bool on) {
+  if (!on) return -1;
+  if (st.m_type == UWSPR_LINEAR && drift != 0.0f) return -1;
+  if (!(set == 0 ? st.tabA_ok : st.tabB_ok)) return -1;
+  if (__float_as_int(centre) != __float_as_int(set == 0 ? st.tabA_f : st.tabB_f)) return -1;
+  return set == 0 ? 0 : kPtabSetB;
+}
+// dev_grp::nvalid bits 16..23 of a lag group (the round-3 lag kernels): 0 = none, else 1 + table index
+__device__ __forceinline__ int ptab_select(const cand_state &st, int set, float f0, float drift, bool on) {
+  return ptab_index(st, set, f0, drift, on) + 1;
+}
+__device__ __forceinline__ void emit_row(dev_row *r, bool on, int frame, int L0, uint32_t mask, int tab) {
+  r->frame = on ? frame : -1; r->L0 = L0; r->mask = mask; r->tab = tab;
 }
 
 __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
                              const int32_t *__restrict__ npk, int cand_stride, int B,
                              int per_frame, float cf, cand_state *__restrict__ state,
-                             dev_hyp *__restrict__ hyps, dev_grp *__restrict__ grps, float2 *__restrict__ ptab) {
+                             dev_hyp *__restrict__ hyps, dev_grp *__restrict__ grps, float2 *__restrict__ ptab,
+                             dev_row *__restrict__ rows) {
   UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
-  // one wavefront per slot: every lane derives the same state (lane 0 writes it), lanes 0..3 build table set A
+  // one wavefront per slot: every lane derives the same state (lane 0 writes it), lanes 0..19 build table set A
   const int slot = blockIdx.x;
   if (slot >= B * per_frame) return;
   const int b = slot / per_frame, j = slot - b * per_frame;
@@ -498,15 +515,17 @@ __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
     st.shift1 = 0; st.sync1 = 0.0f;
   }
   st.worth = 0; st.driftp = 0.0f; st.driftm = 0.0f; st.csync = 0.0f; st.cknown = 0;
-  // table set A: the candidate frequency (S0's lag sweep), when the frequency does not depend on the symbol
-  st.tabA_f = st.f1; st.tabB_f = 0.0f; st.tabB_ok = 0;
+  // S0 (cc:409-415): mode 0, lag = shift1-128 .. shift1+128 step 64, f0 = f1 + 0*0.0f
+  const float f0 = st.f1 + (float)0 * 0.0f;
+  // table set A: f0 + {-2..2} 0.25 Hz (S0's lag sweep at the middle one, S1's five frequencies), when the frequency
+  // does not depend on the symbol.  Built around f0 -- the frequency S0 runs at and S1 is centred on -- not f1: the
+  // two differ in the sign of a zero.
+  st.tabA_f = f0; st.tabB_f = 0.0f; st.tabB_ok = 0;
   st.tabA_ok = (ptab != nullptr && on && (st.m_type != UWSPR_LINEAR || st.drift1 == 0.0f)) ? 1 : 0;
-  if (st.tabA_ok) ptab_build(ptab + (size_t)slot * kPtabPerSlot * kPtabFloat2, 1, 2, st.f1, 0.25f, st.m_type, st.drift1, st.slmc);
+  if (st.tabA_ok) ptab_build(ptab + (size_t)slot * kPtabPerSlot * kPtabFloat2, 5, 0, f0, 0.25f, st.m_type, st.drift1, st.slmc);
   if (threadIdx.x != 0) return;
   state[slot] = st;
-  // S0 (cc:409-415): mode 0, lag = shift1-128 .. shift1+128 step 64, f0 = f1 + 0*0.0f
   dev_hyp *h = hyps + (size_t)slot * 5;
-  const float f0 = st.f1 + (float)0 * 0.0f;
   int lags[5];
   for (int q = 0; q < 5; q++) {
     lags[q] = st.shift1 - 128 + 64 * q;
@@ -514,6 +533,7 @@ __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
   }
   emit_group(&grps[slot], st, on, f0, st.drift1, slot * 5, lags, 5);
   grps[slot].nvalid |= ptab_select(st, 0, f0, st.drift1, on) << 16;
+  emit_row(&rows[slot], on, st.frame, lags[0], 0x1fu, ptab_index(st, 0, f0, st.drift1, on));
 }
 
 template <int STAGE>
@@ -525,7 +545,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
                                                 uwspr_candidate *__restrict__ cent,
                                                 int32_t *__restrict__ cframe, bool reuse, int team = 0,
                                                 int njig = UWSPR_NJIG, int *wsrc = nullptr, bool tabs = false,
-                                                bool fast = false) {
+                                                bool fast = false, dev_row *__restrict__ rows = nullptr) {
   // *wsrc (written by team 0): the input hypothesis whose tone magnitudes are now those of the state's
   // (f1, shift1, drift1) -- the stage winner -- or -1: the winner is the hypothesis that was marked known
   // (its magnitudes are the ones already kept) or nobody won.  The workgroup copies them to the slot's kept
@@ -551,6 +571,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     for (int q = 0; q < 5; q++)
       emit(&ho[q], st, live, st.shift1, st.f1 + (float)(q - 2) * 0.25f, st.drift1, q == 2 && st.cknown);
     emit_centre(&cent[slot], &cframe[slot], st, live);
+    if (rows) emit_row(&rows[slot], live, st.frame, st.shift1, st.cknown ? 0x1bu : 0x1fu, ptab_set(st, 0, st.f1, st.drift1, live));
   } else if (STAGE == 2) {
     // after S1 -> S2 (cc:423-433): linear only, drift1 +- 0.5 at (f1, shift1)
     if (live) {
@@ -588,10 +609,11 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     }
     emit_group(&grps[slot], st, st.worth != 0, f0, st.drift1, slot * 5, lags, 5);
     if (st.cknown) grps[slot].nvalid |= 0x100;   // lag slot 2 is known: K4 skips it
-    // table set B is built around this f1 by the workgroup right after this (k5_fold_step<3>)
-    st.tabB_f = st.f1;
+    // table set B is built around this f0 by the workgroup right after this (k5_fold_step<3>)
+    st.tabB_f = f0;
     st.tabB_ok = (tabs && st.worth && (st.m_type != UWSPR_LINEAR || st.drift1 == 0.0f)) ? 1 : 0;
     grps[slot].nvalid |= ptab_select(st, 1, f0, st.drift1, st.worth != 0) << 16;
+    if (rows) emit_row(&rows[slot], st.worth != 0, st.frame, lags[0], st.cknown ? 0x1bu : 0x1fu, ptab_index(st, 1, f0, st.drift1, st.worth != 0));
   } else if (STAGE == 4) {
     // after S3 -> S4 (cc:449-452): f = f1 + ifreq*0.05
     if (st.worth) {
@@ -604,6 +626,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
       emit(&ho[q], st, st.worth != 0, st.shift1, st.f1 + (float)(q - 2) * 0.05f, st.drift1,
            q == 2 && st.cknown);
     emit_centre(&cent[slot], &cframe[slot], st, st.worth != 0);
+    if (rows) emit_row(&rows[slot], st.worth != 0, st.frame, st.shift1, st.cknown ? 0x1bu : 0x1fu, ptab_set(st, 1, st.f1, st.drift1, st.worth != 0));
   } else {
     // after S4 -> S5 (cc:457-468): 17 jiggered shifts, mode 2
     if (st.worth) {
@@ -616,6 +639,10 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     // reference's arithmetic, so try 0 is correlated again there)
     const bool known0 = reuse && !fast && st.worth && st.sync1 > -1e30f;
     st.cknown = known0 ? 1 : 0;
+    // rows form (eager tries only): m = 0..16 ascending, shift1 - 64 + 8 m; m = 8 is try 0
+    if (rows && team == 0)
+      emit_row(&rows[slot], st.worth != 0 && njig >= UWSPR_NJIG, st.frame, st.shift1 - 64, known0 ? 0x1feffu : 0x1ffffu,
+               ptab_index(st, 1, st.f1, st.drift1, st.worth != 0));
     if (team < njig) {
       const int idt = team;
       int ii = (idt + 1) / 2;
@@ -682,7 +709,8 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
                              const float4 *__restrict__ p, float *__restrict__ sync,
                              dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
                              uwspr_candidate *__restrict__ cent, int32_t *__restrict__ cframe, int nslots,
-                             int reuse, int njig, float4 *__restrict__ pwin, float2 *__restrict__ ptab) {
+                             int reuse, int njig, float4 *__restrict__ pwin, float2 *__restrict__ ptab,
+                             dev_row *__restrict__ rows) {
   UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   constexpr int NIN = STAGE == 3 ? 2 : 5;
   __shared__ k5_wave_lds L[LDS ? (ONEWAVE ? 1 : NIN) : 1];
@@ -703,15 +731,15 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
   __syncthreads();
   if (STAGE == 5) {
     if (threadIdx.x < UWSPR_NJIG + 3)
-      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x, njig, &s_wsrc, ptab != nullptr, FAST);
+      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x, njig, &s_wsrc, ptab != nullptr, FAST, rows);
   } else if (threadIdx.x == 0) {
-    sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, 0, njig, &s_wsrc, ptab != nullptr, FAST);
+    sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, 0, njig, &s_wsrc, ptab != nullptr, FAST, rows);
   }
   __syncthreads();
   if (STAGE == 3 && ptab && threadIdx.x < 64) {   // table set B around the f1 the fine stages start from
     const cand_state st = state[slot];
     if (st.tabB_ok)
-      ptab_build(ptab + ((size_t)slot * kPtabPerSlot + 1) * kPtabFloat2, 5, 0, st.tabB_f, 0.05f, st.m_type, st.drift1, st.slmc);
+      ptab_build(ptab + ((size_t)slot * kPtabPerSlot + kPtabSetB) * kPtabFloat2, 5, 0, st.tabB_f, 0.05f, st.m_type, st.drift1, st.slmc);
   }
   // the stage winner's tone magnitudes become the slot's kept row (cf. k6_sched's keep_winner)
   const int ws = s_wsrc;
@@ -835,7 +863,7 @@ void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t
   prof_scope ps(c, UWSPR_K_SCHED, nslots);
   hipLaunchKernelGGL(k_sched_init, dim3(nslots), dim3(64), 0, c->stream, cands,
                      npk, cand_stride, B, per_frame, (float)c->p.cf, c->d_state, c->d_hyps, c->d_grps,
-                     c->use_ptab ? c->d_ptab : nullptr);
+                     c->use_ptab ? c->d_ptab : nullptr, c->d_rows);
 }
 
 // hyps of consecutive stages ping-pong between the two halves of d_hyps;
@@ -850,7 +878,7 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots, int njig) {
   auto go = [&](auto kern, int threads) {
     hipLaunchKernelGGL(kern, g, dim3(threads), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps,
                        c->d_cent, c->d_cent_frame, nslots, reuse, njig, (float4 *)c->d_pwin,
-                       c->use_ptab ? c->d_ptab : nullptr);
+                       c->use_ptab ? c->d_ptab : nullptr, c->d_rows);
   };
   const bool one = c->k5_onewave;
   if (c->fast_now) {

@@ -100,6 +100,17 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->d_cands = nullptr; c->d_npk = nullptr; c->d_work = nullptr; c->last_B = 0; c->num_cus = 256;
   c->grid_cap = 0; c->cap_grid_bytes = 0; c->d_syncgrid = nullptr;
   c->cap_hyps = 0; c->d_hyps = nullptr; c->cap_grps = 0; c->d_grps = nullptr;
+  c->cap_rows = 0; c->d_rows = nullptr;
+  c->use_rows = !(getenv("UWSPR_K4_ROWS") && atoi(getenv("UWSPR_K4_ROWS")) == 0);
+  {   // wavefronts per tone of a rows workgroup, per stage kind S0,S1,S3,S4,S5 (UWSPR_K4_ROWS_HS="1,1,1,1,2": experiments)
+    static const int dflt[5] = {1, 1, 1, 1, 2};
+    for (int k = 0; k < 5; k++) c->rows_hs[k] = dflt[k];
+    if (const char *e = getenv("UWSPR_K4_ROWS_HS")) {
+      int v[5];
+      if (sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5)
+        for (int k = 0; k < 5; k++) if (v[k] == 1 || v[k] == 2 || (k == 4 && v[k] == 4)) c->rows_hs[k] = v[k];
+    }
+  }
   c->cap_cent = 0; c->d_cent = nullptr; c->d_cent_frame = nullptr; c->cap_abi_hyps = 0; c->d_abi_hyps = nullptr;
   c->cap_p = 0; c->d_p = nullptr; c->cap_sync = 0; c->d_sync = nullptr;
   c->cap_sym = 0; c->d_sym = nullptr; c->cap_state = 0; c->d_state = nullptr;
@@ -288,7 +299,7 @@ extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   (void)uwspr_dist_finalize(c);
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
   void *bufs[] = {c->d_window, c->d_twiddle, c->d_k3_tile, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
-                  c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_cent,
+                  c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_rows, c->d_cent,
                   c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter, c->d_sched_stamps, c->d_pwin, c->d_ptab, c->d_need, c->d_stream_frames, c->d_tmpc, c->d_tmpn};
   for (void *b : bufs) if (b) (void)hipFree(b);
   c->ring.close();
@@ -755,6 +766,7 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
   }
   if ((rc = ensure(c, &c->d_hyps, &c->cap_hyps, 2 * nslots * UWSPR_NJIG))) return rc;
   if ((rc = ensure(c, &c->d_grps, &c->cap_grps, 3 * nslots))) return rc;
+  if ((rc = ensure(c, &c->d_rows, &c->cap_rows, nslots))) return rc;
   // centres (48 B) followed by their frame indices (4 B): 13 int32 per slot in one buffer
   if ((rc = ensure(c, &c->d_cent, &c->cap_cent, (nslots * 13 + 11) / 12 + 1))) return rc;
   c->d_cent_frame = reinterpret_cast<int32_t *>(c->d_cent + nslots);
@@ -785,8 +797,11 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
     else if (c->use_stage_grid && s == 2)
       done = launch_tonecorr_stage_grid(c, dframes, B, (int)nslots, c->d_cent, c->d_cent_frame, 1, zero1,
                                         2, dd2, c->d_p);
+    // the rows form: one workgroup per (slot, third of the symbols), sample-major, phasors by scalar loads
+    static const int rows_kind[6] = {UWSPR_ROWS_S0, UWSPR_ROWS_S1, -1, UWSPR_ROWS_S3, UWSPR_ROWS_S4, UWSPR_ROWS_S5};
     if (done) { /* launched */ }
     else if (lazy && s == 5) launch_tonecorr(c, dframes, B, h, H, c->d_p);   // few, unrelated lags: the plain kernel
+    else if (c->use_rows && use_groups && c->use_ptab && s != 2) launch_tonecorr_rows(c, dframes, B, rows_kind[s], h, (int)nslots, H, c->d_p);
     else if (c->use_fstage && (s == 1 || s == 4)) launch_tonecorr_fstage(c, dframes, B, h, (int)nslots, H, c->d_p);
     else if (use_groups && s == 3 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)nslots, 5, 16, H, c->d_p, 1);
     else if (use_groups && s == 5 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, 8, H, c->d_p, 3);

@@ -76,6 +76,17 @@ struct dev_grp {
 };
 static_assert(sizeof(dev_grp) == 64, "dev_grp is one 64-byte record");
 
+// What the rows form of K4 (k4_rows.hip) computes for a slot in the stage being launched; written by the
+// schedule kernels next to the stage's dev_hyp records.
+struct dev_row {
+  int32_t frame;     // <0: dead slot
+  int32_t L0;        // smallest lag of the stage: hypothesis h has lag L0 + 8 dk8(h)
+  uint32_t mask;     // bit h: hypothesis h is computed (known / unused ones are not)
+  int32_t tab;       // phasor table within the slot (frequency stages: the first of the set's five), -1: the
+                     // frequency depends on the symbol, every lane runs its own recurrences
+};
+enum { UWSPR_ROWS_S0 = 0, UWSPR_ROWS_S1 = 1, UWSPR_ROWS_S3 = 2, UWSPR_ROWS_S4 = 3, UWSPR_ROWS_S5 = 4 };
+
 // per-candidate refinement state kept in HBM between schedule stages
 struct cand_state {
   int32_t frame;       // <0: empty slot
@@ -94,10 +105,11 @@ struct cand_state {
   float tabA_f, tabB_f;
   int32_t tabA_ok, tabB_ok;
 };
-// phasor tables of the staged schedule's lag stages, per slot: table 0 = set A (candidate frequency: S0),
-// tables 1..5 = set B (f1 + {-2..2} 0.05 Hz after S2: S3 uses the middle one, S5 the stage-4 winner's);
-// each [4 tones][256 steps] (c, s) -- the sequence of cc:186-199
-constexpr int kPtabPerSlot = 6;
+// phasor tables of the staged schedule, per slot: tables 0..4 = set A (candidate frequency + {-2..2} 0.25 Hz: S0 uses
+// the middle one, S1 all five), tables 5..9 = set B (f1 + {-2..2} 0.05 Hz after S2: S3 the middle one, S4 all five,
+// S5 the stage-4 winner's); each [4 tones][256 steps] (c, s) -- the sequence of cc:186-199
+constexpr int kPtabPerSlot = 10;
+constexpr int kPtabSetB = 5;           // first table of set B
 constexpr int kPtabFloat2 = 4 * 256;   // float2 per table
 
 struct fdr_consts {
@@ -150,6 +162,9 @@ struct uwspr_ctx {
   int grid_cap; size_t cap_grid_bytes; float *d_syncgrid;  // [B][grid_cap][ntot]
 
   size_t cap_hyps; uwspr::dev_hyp *d_hyps;
+  size_t cap_rows; uwspr::dev_row *d_rows;   // [nslots] of the stage being launched (k4_rows.hip)
+  bool use_rows;         // S0/S1/S3/S4/S5 through the rows form (UWSPR_K4_ROWS=0: the round-3 kernels)
+  int rows_hs[5];        // hypothesis subsets (wavefronts per tone) of a rows workgroup, per stage kind
   size_t cap_grps; uwspr::dev_grp *d_grps;
   size_t cap_cent; uwspr_candidate *d_cent; int32_t *d_cent_frame;   // per-slot grid centres (S1/S2/S4)
   size_t cap_abi_hyps; uwspr_hyp *d_abi_hyps;
@@ -224,6 +239,8 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
 void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
                             int NL, int64_t nhyps, float4 *p, int groups_per_slot = 1);
 void launch_tonecorr_lag0(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int nslots,
+                          int64_t nhyps, float4 *p);
+void launch_tonecorr_rows(uwspr_ctx *c, const float *frames, int B, int kind, const dev_hyp *hyps, int nslots,
                           int64_t nhyps, float4 *p);
 void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int nslots,
                             int64_t nhyps, float4 *p);
