@@ -206,12 +206,11 @@ def main():
     pipes_e2e = {f: G.Pipe(batch_frames=B, max_per_frame=1, lanes=0, sched=f) for f in ("fused", "staged")} if host_legs else {}
     pipe_st = G.Pipe(hop=3375, batch_frames=B, max_per_frame=1, lanes=0) if host_legs else None
 
-    def make_lanes(ns, fused):
-        os.environ["UWSPR_SCHED_FUSED"] = "1" if fused else "0"
+    def make_lanes(ns, fused, extra=None):
         lanes = []
         for k in range(ns):
             st = lane_streams[k]
-            cx = G.Context(device=local)
+            cx = G.Context(device=local, options=dict({"sched": 1 if fused else 0}, **(extra or {})))
             cx.set_stream(st.cuda_stream)
             lanes.append({"stream": st, "ctx": cx,
                           "cands": torch.empty(B * cx.maxfreqs * 48, dtype=torch.uint8, device=dev),
@@ -394,7 +393,7 @@ def main():
     fine_hyps = 10 * nlive + 2 * nlin + 27 * nworth
     # correlations the kernels run: the stage winner repeated by S1/S3/S4 and by try 0 of S5 is carried
     # (both forms since round 3), S0's last lag is its first one symbol later
-    reuse_on = os.environ.get("UWSPR_K4_REUSE", "1") != "0"
+    reuse_on = ctx.get_option("reuse") != 0
     fine_corr = fine_hyps - ((nlive + 3 * nworth) if reuse_on else 0) - nlive
     # binary32 operations those correlations need: 8 per sample, tone and hypothesis; the per-symbol
     # phasor recurrences (6) only where the algorithm cannot share them (the two drift tries of S2)
@@ -457,7 +456,6 @@ def main():
                 "note": "uwspr_set_tries(1), this rank: the reference stops at its first decoding try "
                         "(cc:457-490); the rest is produced on demand by uwspr_demod_resume"}
         close_lanes(lz)
-        os.environ["UWSPR_SCHED_FUSED"] = "1" if fused else "0"
     if world > 1:
         dist.barrier()
 

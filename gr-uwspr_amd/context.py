@@ -37,7 +37,9 @@ class Context:
     (include/uwspr/FDR.h:49-50, include/uwspr/sync_and_demodulate.h:49)."""
 
     def __init__(self, fs=375, fl=45000, spb=256, maxdrift=0, maxfreqs=200, halfbandwidth=10,
-                 cf=1500, threshold=10, device=0):
+                 cf=1500, threshold=10, device=0, options=None):
+        """options: {name: int} for uwspr_set_option ("sched", "stage_kernels", "reuse", "phasor_tables",
+        "fast_search", ...: include/uwspr_hip.h)."""
         self.L = N.lib()
         self.params = N.Params(fs, fl, spb, maxdrift, maxfreqs, halfbandwidth, cf, threshold)
         self.h = C.c_void_p()
@@ -54,6 +56,16 @@ class Context:
         self.fl, self.maxfreqs = fl, maxfreqs
         self._keep = []
         self._stream_ptr = None
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, name, value):
+        self._chk(self.L.uwspr_set_option(self.h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int32()
+        self._chk(self.L.uwspr_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
 
     def close(self):
         if getattr(self, "h", None):
@@ -512,13 +524,13 @@ class Pipe:
 
     def __init__(self, fs=375, fl=45000, spb=256, maxdrift=0, maxfreqs=200, halfbandwidth=10, cf=1500,
                  threshold=10, device=0, hop=3375, batch_frames=256, max_per_frame=1, lanes=0,
-                 host_threads=0, eager=False, sched=None):
+                 host_threads=0, eager=False, sched=None, spare_after_us=0):
         self.L = N.lib()
         self.h = C.c_void_p()
         self.fl = fl
         p = N.Params(fs, fl, spb, maxdrift, maxfreqs, halfbandwidth, cf, threshold)
         o = N.PipeOpts(hop, batch_frames, max_per_frame, lanes, host_threads, 1 if eager else 0,
-                       {None: 0, "fused": 1, "staged": 2}[sched], 0)
+                       {None: 0, "fused": 1, "staged": 2}[sched], int(spare_after_us))
         rc = self.L.uwspr_pipe_open(C.byref(p), device, C.byref(o), C.byref(self.h))
         if rc != 0:
             msg = self.L.uwspr_pipe_last_error(self.h).decode() if self.h else ""

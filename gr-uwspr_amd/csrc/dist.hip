@@ -88,9 +88,9 @@ extern "C" int uwspr_dist_init(uwspr_ctx *c, int rank, int world, const void *id
   if (world < 1 || rank < 0 || rank >= world || (world > 1 && !id128)) return dfail(c, UWSPR_ERR_ARG, "rank %d of %d", rank, world);
   if (c->dist_comm) return dfail(c, UWSPR_ERR_ARG, "uwspr_dist_init: already initialised (uwspr_dist_finalize first)");
   c->dist_rank = rank; c->dist_world = world;
-  // one rank: the gather is a copy -- no communicator, librccl stays unloaded (UWSPR_DIST_FORCE_COMM=1
+  // one rank: the gather is a copy -- no communicator, librccl stays unloaded (option "dist_force_comm"
   // makes a one-rank communicator anyway: a self-test of the RCCL binding on a single-GPU box)
-  if (world == 1 && !(getenv("UWSPR_DIST_FORCE_COMM") && atoi(getenv("UWSPR_DIST_FORCE_COMM")) && id128)) return UWSPR_OK;
+  if (world == 1 && !(c->opt[UWSPR_OPT_DIST_FORCE_COMM] && id128)) return UWSPR_OK;
   rccl_api *r = rccl();
   if (!r) return dfail(c, UWSPR_ERR_UNSUPPORTED, "RCCL unavailable: %s", api.why);
   if (hipSetDevice(c->device) != hipSuccess) return dfail(c, UWSPR_ERR_HIP, "hipSetDevice(%d)", c->device);

@@ -165,7 +165,7 @@ void launch_spectrogram(uwspr_ctx *c, const float *frames, int B) {
   const fdr_consts &f = c->fc;
   prof_scope ps(c, UWSPR_K_SPECTROGRAM, B);
   int rpw = B >= K1_LARGE_BATCH ? K1_ROWS_LARGE : K1_ROWS_SMALL;
-  if (const char *e = getenv("UWSPR_K1_ROWS")) { if (atoi(e) > 0) rpw = atoi(e); }   // A/B only
+  if (c->opt[UWSPR_OPT_K1_ROWS] > 0) rpw = c->opt[UWSPR_OPT_K1_ROWS];   // (option "k1_rows": A/B only)
   const int items = B * ((f.n + rpw - 1) / rpw);
   dim3 grid((items + K1_WAVES - 1) / K1_WAVES);
   const bool narrow = f.band_lo >= 192 && f.band_lo + f.band_w <= 320;

@@ -430,13 +430,12 @@ size_t coarse_lds_bytes(const fdr_consts &f) { return k3_layout(f).total; }
 int coarse_seq_words() { return K3_SEQ_WORDS; }
 // Picks the tile form and its row pitch (f.k3_mode, f.tp); returns the floats of HBM scratch one
 // workgroup needs (0 unless the tile lives in HBM).
-size_t coarse_plan(fdr_consts &f) {
+size_t coarse_plan(fdr_consts &f, int pitch_opt, int tile_opt) {   // options "k3_pitch", "k3_tile"
   // measured: pitch 24 instead of 13 made the kernel 3 % faster for 61 KB more LDS (the conflicts
   // are not what bounds the gather loop) -- the compact tile stays the default
   int want = f.nc;
-  if (const char *e = getenv("UWSPR_K3_PITCH")) { if (atoi(e) >= f.nc) want = atoi(e); }
-  int force = -1;
-  if (const char *e = getenv("UWSPR_K3_TILE")) force = atoi(e);   // tests: 0 / 1 / 2
+  if (pitch_opt >= f.nc) want = pitch_opt;
+  const int force = tile_opt;   // tests: 0 / 1 / 2
   f.k3_mode = K3_TILE_F4;
   if (force <= K3_TILE_F4) {
     f.tp = want;

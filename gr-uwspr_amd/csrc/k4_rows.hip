@@ -142,6 +142,7 @@ __global__ __launch_bounds__(256 * HS) __attribute__((amdgpu_waves_per_eu(3 * HS
   const unsigned wg = xcd_swizzle(blockIdx.x, gridDim.x);
   const int slot = (int)(wg / 3u), third = (int)(wg % 3u);
   if (slot >= nslots) return;   // workgroup-uniform
+  const unsigned prio_class = blockIdx.x / ((gridDim.x + 2u) / 3u);
 
   const dev_row R = rows[slot];
   const bool live = R.frame >= 0 && R.frame < nframes;
@@ -230,6 +231,17 @@ __global__ __launch_bounds__(256 * HS) __attribute__((amdgpu_waves_per_eu(3 * HS
 #endif
     if (u) { gstore((u >> 2) & 1); tstore((u >> 2) & 1); __syncthreads(); }
     gload(min((u >> 2) + 1, nch - 1)); tload(min((u >> 2) + 1, nch - 1));
+    // Issue priority, rotated chunk by chunk over the three workgroups that share a CU (workgroups b, b + G/3,
+    // b + 2G/3 of a grid of G land on the same CU: tools/kr_wgmap.py).  The arbiter serves equal priorities oldest
+    // first, so without this the first of the three runs ahead and the last one finishes 15 us after it -- alone on
+    // its SIMDs, at two wavefronts each.  Taking turns keeps the three in step and the SIMDs full to the end.
+#ifndef KR_NO_PRIO_ROTATION
+    switch (((unsigned)(u >> 2) + prio_class) % 3u) {   // (the instruction takes an immediate; uniform branch)
+      case 0: __builtin_amdgcn_s_setprio(0); break;
+      case 1: __builtin_amdgcn_s_setprio(1); break;
+      default: __builtin_amdgcn_s_setprio(2); break;
+    }
+#endif
 #ifdef KR_STAMPS
     st_bar += __builtin_amdgcn_s_memtime() - t0;
 #endif
@@ -391,7 +403,7 @@ __global__ __launch_bounds__(256 * HS) __attribute__((amdgpu_waves_per_eu(3 * HS
     if (gw < (unsigned)KR_STAMP_WAVES) {
       unsigned long long *o = &g_kr_stamps[(size_t)gw * 8];
       o[0] = st_c0; o[1] = __builtin_amdgcn_s_memtime(); o[2] = st_r0; o[3] = __builtin_amdgcn_s_memrealtime();
-      o[4] = st_pro; o[5] = st_end - st_c0 - st_pro - st_bar; o[6] = st_bar;
+      o[4] = blockIdx.x; o[5] = st_end - st_c0 - st_pro - st_bar; o[6] = st_bar;
       o[7] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     }
   }

@@ -29,7 +29,6 @@
 // Work per pair-sample: 32 correlation + 24 phasor binary32 ops = 56 VALU ops;
 // the kernel is FP32-VALU bound; HBM sees each frame about once
 // (L2 / Infinity Cache serve the re-reads by the other hypotheses of the frame).
-#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -47,7 +46,9 @@ constexpr int K4_ROWDW = 36;  // dwords per staged row: 16 samples x 8 B + 16 B 
 template <int T, bool FAST = false>
 __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
     const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_hyp *__restrict__ hyps,
-    int H, float *__restrict__ p_out) {
+    int H, float *__restrict__ p_out, const dev_grp *__restrict__ taken, int hyps_per_grp) {
+  // taken (or null): hypothesis h belongs to group h / hyps_per_grp; groups that have their phasor table
+  // (dev_grp::nvalid bits 16..23) were computed by another kernel (k4_lag0) -- left alone here, nothing stored
   constexpr int PPW = 16 * T;        // pairs per wavefront
   constexpr int LPP = 4 / T;         // lanes per pair
   constexpr int NLD = PPW / 4;       // cooperative loads per lane per chunk
@@ -67,8 +68,10 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
   const int sb = min(PPW, UWSPR_NSYM - iA0);  // pairs < sb belong to hA
   dev_hyp A = hyps[hA];
   dev_hyp Bh = hyps[min(hA + 1, H - 1)];
-  const bool okA = A.frame >= 0 && A.frame < nframes;
-  const bool okB = (hA + 1 < H) && Bh.frame >= 0 && Bh.frame < nframes;
+  const bool takenA = taken && ((taken[hA / hyps_per_grp].nvalid >> 16) & 0xff) != 0;
+  const bool takenB = taken && ((taken[min(hA + 1, H - 1) / hyps_per_grp].nvalid >> 16) & 0xff) != 0;
+  const bool okA = A.frame >= 0 && A.frame < nframes && !takenA;
+  const bool okB = (hA + 1 < H) && Bh.frame >= 0 && Bh.frame < nframes && !takenB;
   // hypotheses that are skipped still own LDS rows: point them at safe samples
   if (!okA) { A.frame = 0; A.lag = 1 - 256 * iA0; }
   if (!okB) { Bh.frame = 0; Bh.lag = 1; }
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
   const bool own_ok = mineA ? okA : (okB && (g0 + pr) < total);
   // nothing live in this wavefront (a noise-only stream leaves most candidates' later stages dead): zeros, done
   if (!okA && !(okB && sb < PPW)) {   // wave-uniform
-    if (g0 + pr < total) {
+    if (g0 + pr < total && !(mineA ? takenA : takenB)) {
       float *out = p_out + (g0 + pr) * 4 + tone0;
 #pragma unroll
       for (int j = 0; j < T; j++) out[j] = 0.0f;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
     }
   }
 
-  if (g0 + pr < total) {
+  if (g0 + pr < total && !(mineA ? takenA : takenB)) {
     float *out = p_out + (g0 + pr) * 4 + tone0;  // p[pair][tone]
 #pragma unroll
     for (int j = 0; j < T; j++) {
@@ -189,295 +192,46 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
   }
 }
 
-static int k4_choose_t(long long pairs) {
-  static int forced = -1;
-  if (forced < 0) {
-    const char *e = getenv("UWSPR_K4_T");
-    forced = e ? atoi(e) : 0;
-  }
-  if (forced == 1 || forced == 2 || forced == 4) return forced;
-  // enough wavefronts to fill 256 CUs x 4 SIMDs several times over -> amortise
-  if (pairs >= 1024 * 1024) return 2;   // T=4 (2 waves/SIMD at 200+ VGPRs) measured no faster
-  return 1;
-}
-
 void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int H,
-                     float4 *p) {
+                     float4 *p, const dev_grp *taken, int hyps_per_grp) {
   if (H <= 0) return;
   prof_scope ps(c, UWSPR_K_TONECORR, H, true);
   const long long total = (long long)H * UWSPR_NSYM;
-  const int T = k4_choose_t(total);
+  // T = tones per lane: 1 for the schedule's few-hypothesis stages (4x the wavefronts, a 4x shorter serial chain),
+  // 2 from a million pairs up (the sweeps: amortise the sample reads; T = 4 -- 2 waves/SIMD at 200+ VGPRs -- measured
+  // no faster).  Option "k4_t" forces it.
+  int T = c->opt[UWSPR_OPT_K4_T];
+  if (T != 1 && T != 2 && T != 4) T = total >= 1024 * 1024 ? 2 : 1;
   const long long waves = (total + 16 * T - 1) / (16 * T);
   const unsigned blocks = (unsigned)((waves + K4_WAVES - 1) / K4_WAVES);
   const float2 *fr = (const float2 *)frames;
   float *po = (float *)p;
   dim3 blk(64 * K4_WAVES);
-  if (T == 1 && c->fast_now) launch_timed(c, ps, (k4_tonecorr<1, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po);
-  else if (T == 1) launch_timed(c, ps, k4_tonecorr<1>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po);
-  else if (T == 2) launch_timed(c, ps, k4_tonecorr<2>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po);
-  else launch_timed(c, ps, k4_tonecorr<4>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po);
+  if (hyps_per_grp < 1) hyps_per_grp = 1;
+  if (T == 1 && c->fast_now) launch_timed(c, ps, (k4_tonecorr<1, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po, taken, hyps_per_grp);
+  else if (T == 1) launch_timed(c, ps, k4_tonecorr<1>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po, taken, hyps_per_grp);
+  else if (T == 2) launch_timed(c, ps, k4_tonecorr<2>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po, taken, hyps_per_grp);
+  else launch_timed(c, ps, k4_tonecorr<4>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po, taken, hyps_per_grp);
 }
 
 }  // namespace uwspr
 
-// ---------------------------------------------------------------------------
-// Lag-group form.  The reference's lag sweeps (mode 0, cc:165; the 17 jiggered
-// shifts cc:457-468) and any (freq, lag, drift) grid evaluate several time lags
-// at the SAME per-symbol frequencies: the tone phasor tables c[j][k], s[j][k]
-// (cc:186-199) are identical for all of them -- the reference itself caches them
-// across lags via `fplast`.  Here a lane owns one (group, symbol) pair and one
-// tone, advances that tone's phasor once per sample, and accumulates inp/quad
-// for all NL lags of the group against it: 6 + 8*NL ops per sample instead of
-// 14*NL, every accumulator still seeing the reference's exact operation order.
-// LDS rows are (lag, pair); the loader brings 16 samples per row per chunk.
 namespace uwspr {
 
-constexpr int K4G_WAVES = 2;
-
-#ifdef K4_STAMPS   // diagnostic build only: per-wave timeline of the last k4_group launch
-constexpr int K4_STAMP_WAVES = 16384;
-__device__ unsigned long long g_k4_stamps[K4_STAMP_WAVES * 4];
-#ifndef K4_STAMP_NL
-#define K4_STAMP_NL 5
-#endif
-#define K4_STAMP(slot) do { if (NL == K4_STAMP_NL && lane == 0 && gwave < K4_STAMP_WAVES) g_k4_stamps[gwave * 4 + (slot)] = wall_clock64(); } while (0)
-#else
-#define K4_STAMP(slot) do { } while (0)
-#endif
-
-// skip_tabled: groups whose phasor table exists (nvalid bits 16..23) were done by k4_lag0 and are left alone
-template <int NL, bool FAST = false>
-__global__ __launch_bounds__(64 * K4G_WAVES) void k4_group(
-    const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_grp *__restrict__ grps,
-    int G, float *__restrict__ p_out, int skip_tabled) {
-  constexpr int PPW = 16;                  // (group, symbol) pairs per wavefront, 4 tone lanes each
-  constexpr int NLP = (NL + 1) & ~1;       // lags per sample slot, padded to even (16-B aligned slots)
-  constexpr int ROWDW = 32 * NLP + 4;      // dwords per pair row: [16 samples][NLP lags] float2 + 16 B pad
-  constexpr int NLD = 4 * NL;              // cooperative loads per lane per chunk
-  __shared__ __align__(16) float lds_all[K4G_WAVES][PPW * ROWDW];
-
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float *lds = lds_all[wv];
-
-  const long long total = (long long)G * UWSPR_NSYM;
-  const unsigned lblock = xcd_swizzle(blockIdx.x, gridDim.x);
-  const long long g0 = ((long long)lblock * K4G_WAVES + wv) * PPW;
-  if (g0 >= total) return;  // wave-uniform
-#ifdef K4_STAMPS
-  const int gwave = lblock * K4G_WAVES + wv;
-  K4_STAMP(0);
-  if (NL == K4_STAMP_NL && lane == 0 && gwave < K4_STAMP_WAVES)
-    g_k4_stamps[gwave * 4 + 3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
-                                 ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-#endif
-
-  const int gA = (int)(g0 / UWSPR_NSYM);
-  const int iA0 = (int)(g0 - (long long)gA * UWSPR_NSYM);
-  const int sb = min(PPW, UWSPR_NSYM - iA0);  // pairs < sb belong to group gA
-  const dev_grp A = grps[gA];
-  const dev_grp Bg = grps[min(gA + 1, G - 1)];
-  const bool doneA = skip_tabled && ((A.nvalid >> 16) & 0xff) != 0, doneB = skip_tabled && ((Bg.nvalid >> 16) & 0xff) != 0;
-  const bool okA = A.frame >= 0 && A.frame < nframes && !doneA;
-  const bool okB = (gA + 1 < G) && Bg.frame >= 0 && Bg.frame < nframes && !doneB;
-  if (skip_tabled && !okA && !(okB && UWSPR_NSYM - iA0 < PPW)) return;   // nothing of this wavefront is ours (wave-uniform)
-  const int frA = okA ? A.frame : 0, frB = okB ? Bg.frame : 0;
-  const int nvA = okA ? (A.nvalid & 0xff) : 0, nvB = okB ? (Bg.nvalid & 0xff) : 0;   // bit 8: see k4_ring
-  // lag of slot l for the two groups; skipped groups / unused slots point at safe samples
-  int la[NL], lb[NL];
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    la[l] = l < nvA ? A.lag[l] : (nvA > 0 ? A.lag[0] : 1 - 256 * iA0);
-    lb[l] = l < nvB ? Bg.lag[l] : (nvB > 0 ? Bg.lag[0] : 1);
-  }
-
-  const int pr = lane >> 2;
-  const int tone = lane & 3;
-  const bool mineA = pr < sb;
-  const int own_i = mineA ? iA0 + pr : pr - sb;
-  bool inside = true;
-#pragma unroll
-  for (int l = 0; l < NL; l++) {
-    const int nb = (mineA ? la[l] : lb[l]) + 256 * own_i;
-    inside = inside && (nb > 0) && (nb + 255 < np);
-  }
-  const bool interior = __all(inside);
-
-  // One-symbol wrap (S0: lags shift-128 .. shift+128): when the last lag is exactly one symbol
-  // (256 samples) after the first and the per-symbol frequency does not depend on the symbol,
-  // symbol i at the last lag reads the samples of symbol i+1 at the first lag against the same
-  // phasors -- the same numbers.  Such a group correlates NL-1 lags; the lane of symbol i+1
-  // stores its first-lag result for (last lag, symbol i) as well.  Only the wavefront that holds
-  // symbol 161 (no successor) walks all NL lags.
-  auto wraps = [&](const dev_grp &g, bool ok) {
-    return NL == 5 && ok && (g.nvalid & 0xff) == NL && g.lag[NL - 1] - g.lag[0] == 256 &&
-           (g.m_type != UWSPR_LINEAR || g.drift == 0.0f);
-  };
-  const bool wrapA = wraps(A, okA), wrapB = wraps(Bg, okB);
-  const bool hasB = sb < PPW;
-  const bool all_lags = (okA && !wrapA) || (hasB && okB && !wrapB) ||
-                        (okA && iA0 + sb - 1 >= UWSPR_NSYM - 1);   // wave-uniform
-
-  // ---- this lane's tone phasor step (binary64 angle, cc:173-189) ------------
-  float cd, sd;
-  {
-    const dev_grp &gy = mineA ? A : Bg;
-    float fp;
-    if (gy.m_type == UWSPR_LINEAR) {
-      fp = (float)((double)gy.f0 +
-                   ((double)gy.drift / 2.0) * ((double)(float)own_i - 81.0) / 81.0);
-    } else {
-      fp = gy.f0 + gy.slmc;
-    }
-    const float delta = ((float)tone - 1.5f) * 1.46484375f;
-    double sn, cs;
-    sincos(kTwoPiDt * (double)(fp + delta), &sn, &cs);
-    cd = (float)cs;
-    sd = (float)sn;
-  }
-
-  // ---- cooperative loader: load t = (lag t/4, pair slot 4(t%4) + lane/16), sample lane%16
-  const int kk = lane & 15;
-  const int segq = lane >> 4;
-  // element offsets relative to the wave's first frame (wave-uniform base pointer)
-  const float2 *wbase = frames + (long long)frA * fstride;
-  int eoff[4];
-  bool slotA[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int pj = 4 * j + segq;
-    slotA[j] = pj < sb;
-    eoff[j] = slotA[j] ? 256 * (iA0 + pj) + kk : (frB - frA) * fstride + 256 * (pj - sb) + kk;
-  }
-  // rows whose frame is further than 2^31 samples from the first one take the general path
-  const bool near = ((long long)(frB - frA) * fstride < (1LL << 30)) && ((long long)(frB - frA) * fstride > -(1LL << 30));
-
-  const bool fast = interior && near;  // wave-uniform
-  float2 stage[NLD];
-  float c = 1.0f, s = 0.0f;
-  float inp[NL], quad[NL];
-#pragma unroll
-  for (int l = 0; l < NL; l++) { inp[l] = 0.0f; quad[l] = 0.0f; }
-
-  auto walk = [&](auto nlw_tag) {
-  constexpr int NLW = decltype(nlw_tag)::value;   // lags this wavefront walks (NL, or NL-1 with the wrap)
-  constexpr int NLDW = 4 * NLW;
-  auto load_chunk = [&](int c) {
-    if (fast) {
-#pragma unroll
-      for (int t = 0; t < NLDW; t++) {
-        const int l = t >> 2, j = t & 3;
-        stage[t] = wbase[eoff[j] + (slotA[j] ? la[l] : lb[l]) + 16 * c];
-      }
-    } else {
-#pragma unroll
-      for (int t = 0; t < NLDW; t++) {
-        const int l = t >> 2, j = t & 3;
-        const int lag = slotA[j] ? la[l] : lb[l];
-        const int n = (slotA[j] ? 256 * (iA0 + 4 * j + segq) : 256 * (4 * j + segq - sb)) + kk + lag + 16 * c;
-        const bool inr = (n > 0) && (n < np);  // cc:205, sample 0 excluded
-        const long long fb = (long long)(slotA[j] ? frA : frB) * fstride;
-        const float2 v = frames[fb + min(max(n, 0), np - 1)];
-        stage[t] = inr ? v : make_float2(0.0f, 0.0f);
-      }
-    }
-  };
-
-  K4_STAMP(1);
-  load_chunk(0);
-  for (int ch = 0; ch < 16; ch++) {
-    wave_lds_fence();
-#pragma unroll
-    for (int t = 0; t < NLDW; t++) {
-      const int l = t >> 2, j = t & 3;
-      *reinterpret_cast<float2 *>(&lds[(4 * j + segq) * ROWDW + (kk * NLP + l) * 2]) = stage[t];
-    }
-    wave_lds_fence();
-    if (ch < 15) load_chunk(ch + 1);
-    // the NL lags of a sample slot are contiguous (16-byte reads); the reads of step k+1
-    // are issued before the arithmetic of step k so their LDS latency is covered
-    auto read_slot = [&](int k, float2 (&x)[NLP]) {
-      const float *slot = &lds[pr * ROWDW + k * NLP * 2];
-#pragma unroll
-      for (int q = 0; q < (NLW + 1) / 2; q++) {
-        if (2 * q + 1 < NLW) {
-          const float4 v = *reinterpret_cast<const float4 *>(slot + 4 * q);
-          x[2 * q] = make_float2(v.x, v.y); x[2 * q + 1] = make_float2(v.z, v.w);
-        } else {
-          x[2 * q] = *reinterpret_cast<const float2 *>(slot + 4 * q);
-        }
-      }
-    };
-    float2 xc[NLP], xn[NLP];
-#pragma unroll
-    for (int l = 0; l < NLP; l++) { xc[l] = make_float2(0.0f, 0.0f); xn[l] = xc[l]; }
-    read_slot(0, xc);
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      if (k < 15) read_slot(k + 1, xn);
-#pragma unroll
-      for (int l = 0; l < NLW; l++) k4_mac<FAST>(inp[l], quad[l], xc[l].x, xc[l].y, c, s);   // cc:206-207
-      k4_rot<FAST>(c, s, cd, sd);                          // cc:193-195
-#pragma unroll
-      for (int l = 0; l < NLP; l++) xc[l] = xn[l];
-    }
-  }
-  };   // walk
-  if (all_lags) walk(std::integral_constant<int, NL>{});
-  else walk(std::integral_constant<int, (NL == 5 ? NL - 1 : NL)>{});
-
-  K4_STAMP(2);
-  if (g0 + pr < total) {
-    const int nv = mineA ? nvA : nvB;
-    const int hb = mineA ? A.hyp_base : Bg.hyp_base;
-    const uint32_t hm = mineA ? A.hmap : Bg.hmap;
-    const bool wrap = mineA ? wrapA : wrapB;
-#pragma unroll
-    for (int l = 0; l < NL; l++) {
-      if (l < nv && (all_lags || l < NL - 1 || NL != 5)) {
-        const float pj = ieee_sqrtf(inp[l] * inp[l] + quad[l] * quad[l]);  // cc:211
-        p_out[((long long)(hb + (int)((hm >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = pj;
-        // the wrap: (first lag, symbol i) is also (last lag, symbol i-1)
-        if (NL == 5 && l == 0 && wrap && own_i >= 1)
-          p_out[((long long)(hb + (int)((hm >> (4 * (NL - 1))) & 15u)) * UWSPR_NSYM + own_i - 1) * 4 + tone] = pj;
-      }
-    }
-    // groups that are skipped produce zeros for their hypotheses
-    const dev_grp &gy = mineA ? A : Bg;
-    if (!(mineA ? okA : okB) && !(mineA ? doneA : doneB) && (gy.nvalid & 0xff) > 0)
-      for (int l = 0; l < (gy.nvalid & 0xff) && l < NL; l++)
-        p_out[((long long)(gy.hyp_base + (int)((gy.hmap >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
-  }
-}
-
-void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
-                            int NL, int64_t nhyps, float4 *p, int gps) {
-  if (G <= 0) return;
-  prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
-  const long long total = (long long)G * UWSPR_NSYM;
-  const long long waves = (total + 15) / 16;
-  const unsigned blocks = (unsigned)((waves + K4G_WAVES - 1) / K4G_WAVES);
-  const float2 *fr = (const float2 *)frames;
-  float *po = (float *)p;
-  dim3 blk(64 * K4G_WAVES);
-  const int skip = c->group_skip_tabled ? 1 : 0;   // set around stage 0 when k4_lag0 took the tabled slots
-  if (NL == 5 && c->fast_now) launch_timed(c, ps, (k4_group<5, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, skip);
-  else if (NL == 5) launch_timed(c, ps, k4_group<5>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, skip);
-  else if (NL == 6) launch_timed(c, ps, k4_group<6>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, skip);
-  else launch_timed(c, ps, k4_group<8>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, skip);
-}
+constexpr int K4G_WAVES = 2;   // wavefronts per workgroup of the ring form
 
 // ---------------------------------------------------------------------------
-// Ring form of the lag group, for groups whose lags are ASCENDING and evenly
-// spaced by STEP samples (S3: shift1-32..+32 step 16; S5: the jiggered shifts,
+// Ring form of a lag group (dev_grp: up to 8 hypotheses that differ only in their time lag and so share their
+// tone phasors -- the reference itself caches the tone tables across lags via `fplast`), for groups whose lags
+// are ASCENDING and evenly spaced by STEP samples (S3: shift1-32..+32 step 16; S5: the jiggered shifts,
 // step 8).  The NL windows of a (group, symbol) pair overlap almost entirely, so
 // the pair's samples a = n - (lag[0] + 256 i), 0 <= a < 256 + (NL-1) STEP, are
 // brought into LDS ONCE, as a ring of M = Q+1 slots of 16 samples, instead of
 // once per lag: 4 global loads and 4 LDS stores per lane and 16-sample chunk
 // instead of 4 NL.  Lag l at step k of chunk c reads a = 16 c + k + STEP l, i.e.
 // slot (c + q) mod M, column r with (q, r) = divmod(k + STEP l, 16) known at
-// compile time; the M slot addresses rotate once per chunk.  Arithmetic per
-// accumulator is exactly k4_group's (cc:193-195, 206-207).
+// compile time; the M slot addresses rotate once per chunk.  Every accumulator sees the
+// reference's operation sequence (cc:193-195, 206-207).
 // Phasor tables (k5_fold_schedule.hip: ptab_build; dev_grp::nvalid bits 16..23 = 1 + table of the slot, 0 = none):
 // when every live group of a wavefront has one, the lanes do not run the recurrence (six instruction slots per
 // sample step) but read c[k], s[k] from a 16-step slice the wavefront fetches per chunk into LDS.
@@ -756,10 +510,7 @@ void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_gr
                           int NL, int step, int64_t nhyps, float4 *p, int gps) {
   if (G <= 0) return;
   const bool r5 = NL == 5 && step == 16, r6 = NL == 6 && step == 8;
-  if (!r5 && !r6) {   // no ring instance for this spacing: plain lag groups
-    launch_tonecorr_groups(c, frames, B, grps, G, NL <= 5 ? 5 : NL == 6 ? 6 : 8, nhyps, p, gps);
-    return;
-  }
+  if (!r5 && !r6) return;   // (the schedule emits exactly these two spacings)
   prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
   const long long total = (long long)G * UWSPR_NSYM;
   const long long waves = (total + 15) / 16;
@@ -778,202 +529,21 @@ void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_gr
 }  // namespace uwspr
 
 // ---------------------------------------------------------------------------
-// Frequency-stage form, for the schedule's S1 / S4: the NF hypotheses of a
-// candidate slot share frame, lag and drift model and differ only in f0
-// (cc:416-419, 449-452).  A workgroup of four wavefronts -- one per TONE -- takes
-// 54 of the slot's 162 symbols, one symbol per lane, and every lane correlates its
-// symbol window against all NF frequencies: the window is staged and read once
-// for NF hypotheses.  When the per-symbol frequency does not depend on the symbol
-// (drift == 0 or the nonlinear model: the usual case), the phasor sequence
-// c[k], s[k] (cc:186-199) is the same for all symbols of a (frequency, tone) --
-// the reference caches it via `fplast` for the same reason -- so NF lanes of each
-// wave advance the NF recurrences, publish 16 steps at a time in LDS, and the
-// other lanes only multiply-accumulate: 8 NF ops per sample and lane plus 6 ops
-// on NF lanes, instead of 14 NF.  With a per-symbol frequency (drifting linear
-// model) every lane runs its own recurrences as k4_tonecorr does.  Arithmetic
-// per accumulator and per phasor is the reference's sequence in both cases.
+// The schedule's S0 (k4_lag0) and S1 / S4 (k4_fpack) on packed rows: the (slot, symbol) pairs of the whole launch
+// are flattened and a workgroup of four wavefronts -- one per TONE -- takes 64 consecutive ones, one per lane.
 namespace uwspr {
 
-constexpr int K4F_PAIRS = 54;   // symbols per workgroup: 162 = 3 x 54
 #ifndef K4F_CHUNK
 #define K4F_CHUNK 32
 #endif
 
-template <int NF, int CH, bool FAST = false>   // CH = samples per staged chunk (16 or 32)
-__global__ __launch_bounds__(256) void k4_fstage(
-    const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_hyp *__restrict__ hyps,
-    int nslots, float *__restrict__ p_out, int onegen) {
-  constexpr int K4F_ROWDW = 2 * CH + 4;   // dwords per staged row: CH samples x 8 B + 16 B pad (16-byte aligned)
-  constexpr int NCH = 256 / CH;           // chunks per symbol
-  constexpr int SEGS = 256 / CH;          // symbols staged per loader round
-  constexpr int NR = (K4F_PAIRS + SEGS - 1) / SEGS;
-  __shared__ __align__(16) float smp[K4F_PAIRS * K4F_ROWDW];
-  __shared__ __align__(16) float4 tab[4][CH / 2][NF];   // (c, s) of steps 2j and 2j+1 per frequency
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int tone = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned wg = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int slot = (int)(wg / 3u), part = (int)(wg % 3u);
-  if (slot >= nslots) return;  // workgroup-uniform
-
-  const dev_hyp h0 = hyps[(size_t)slot * NF];
-  float f0[NF];
-#pragma unroll
-  for (int q = 0; q < NF; q++) f0[q] = hyps[(size_t)slot * NF + q].f0;
-  const bool live = h0.frame >= 0 && h0.frame < nframes;
-  const int row = min(lane, K4F_PAIRS - 1);
-  const int own_i = part * K4F_PAIRS + row;       // this lane's symbol
-  const bool mine = lane < K4F_PAIRS;
-  if (!live) {                                     // skipped slot: its hypotheses read as zeros
-    if (mine)
-#pragma unroll
-      for (int q = 0; q < NF; q++)
-        p_out[(((long long)slot * NF + q) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
-    return;
-  }
-  const bool tabled = (h0.m_type != UWSPR_LINEAR) || (h0.drift == 0.0f);   // fp independent of the symbol
-  // the middle frequency repeats the previous stage's winner when marked (frame <= -2): nobody
-  // reads its p[], so it is left out
-  const bool skip_mid = hyps[(size_t)slot * NF + NF / 2].frame <= -2;
-  const float delta = ((float)tone - 1.5f) * 1.46484375f;                    // cc:148
-
-  // ---- loader: round r of a chunk = symbol SEGS r + tid/CH, sample tid%CH ----
-  const int kk = tid % CH, seg = tid / CH;
-  const float2 *fb = frames + (long long)h0.frame * fstride;
-  const int nb0 = h0.lag + 256 * (part * K4F_PAIRS);
-  const bool interior = (nb0 > 0) && (nb0 + 256 * K4F_PAIRS < np);          // workgroup-uniform
-  float2 stage[NR];
-  int nrow[NR];
-#pragma unroll
-  for (int r = 0; r < NR; r++) nrow[r] = nb0 + 256 * min(SEGS * r + seg, K4F_PAIRS - 1) + kk;
-  auto load_chunk = [&](int c) {
-    if (interior) {
-#pragma unroll
-      for (int r = 0; r < NR; r++) stage[r] = fb[nrow[r] + CH * c];
-    } else {
-#pragma unroll
-      for (int r = 0; r < NR; r++) {
-        const int n = nrow[r] + CH * c;
-        const bool inr = (n > 0) && (n < np);      // cc:205, sample 0 excluded
-        const float2 v = fb[min(max(n, 0), np - 1)];
-        stage[r] = inr ? v : make_float2(0.0f, 0.0f);
-      }
-    }
-  };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int r = 0; r < NR; r++) {
-      const int pj = SEGS * r + seg;
-      if (pj < K4F_PAIRS) *reinterpret_cast<float2 *>(&smp[pj * K4F_ROWDW + 2 * kk]) = stage[r];
-    }
-  };
-
-  float inp[NF], quad[NF];
-#pragma unroll
-  for (int q = 0; q < NF; q++) { inp[q] = 0.0f; quad[q] = 0.0f; }
-
-  if (tabled) {
-    // The NF x 4 recurrences (frequency, tone) of the workgroup all run on lanes 0..4 NF - 1 of wavefront 0:
-    // a recurrence step costs the wavefront that runs it six instruction slots however few lanes are
-    // active, so one wavefront generating every tone's table (instead of each wavefront its own tone's)
-    // takes 3/4 of that overhead out (-2 % of the whole step's VALU instructions).
-    float cq = 1.0f, sq = 0.0f, cdq = 1.0f, sdq = 0.0f;
-    // (onegen == 0, UWSPR_K4F_ONEGEN=0: every wavefront generates its own tone's NF tables -- same values)
-    const int gq = onegen ? lane % NF : min(lane, NF - 1);              // this lane's (frequency, tone) as a generator
-    const int gt = onegen ? min(lane / NF, 3) : tone;
-    const bool gen = onegen ? (tone == 0) && (lane < 4 * NF) : (lane < NF);
-    if (gen) {
-      float fq = f0[0];
-#pragma unroll
-      for (int q = 1; q < NF; q++) fq = (gq == q) ? f0[q] : fq;
-      const float fp = (h0.m_type == UWSPR_LINEAR)
-                           ? (float)((double)fq + ((double)h0.drift / 2.0) * ((double)(float)0 - 81.0) / 81.0)
-                           : fq + h0.slmc;                                   // cc:173 / cc:179 (drift == 0)
-      const float gdelta = ((float)gt - 1.5f) * 1.46484375f;                 // cc:148
-      double sn, cs;
-      sincos(kTwoPiDt * (double)(fp + gdelta), &sn, &cs);
-      cdq = (float)cs;
-      sdq = (float)sn;
-    }
-    load_chunk(0);
-    auto walk = [&](auto skip_tag) {
-      constexpr bool SKIP = decltype(skip_tag)::value;
-      for (int ch = 0; ch < NCH; ch++) {
-        __syncthreads();              // the previous chunk has been read by everyone
-        store_chunk();
-        if (gen) {
-#pragma unroll
-          for (int k = 0; k < CH; k++) {
-            reinterpret_cast<float2 *>(&tab[gt][k >> 1][gq])[k & 1] = make_float2(cq, sq);
-            k4_rot<FAST>(cq, sq, cdq, sdq);         // cc:193-195
-          }
-        }
-        __syncthreads();
-        load_chunk(min(ch + 1, NCH - 1));  // in flight during the arithmetic (no branch around it)
-#pragma unroll
-        for (int k = 0; k < CH; k += 2) {
-          // two samples and two phasor steps per LDS read (ds_read_b128)
-          const float4 x = *reinterpret_cast<const float4 *>(&smp[row * K4F_ROWDW + 2 * k]);
-#pragma unroll
-          for (int q = 0; q < NF; q++) {
-            if (SKIP && q == NF / 2) continue;
-            const float4 ph = tab[tone][k >> 1][q];   // same address in every lane: LDS broadcast
-            k4_mac<FAST>(inp[q], quad[q], x.x, x.y, ph.x, ph.y);      // cc:206-207, step k
-            k4_mac<FAST>(inp[q], quad[q], x.z, x.w, ph.z, ph.w);      // step k + 1
-          }
-        }
-      }
-    };
-    if (skip_mid) walk(std::true_type{}); else walk(std::false_type{});
-  } else {
-    float c[NF], s[NF], cd[NF], sd[NF];
-#pragma unroll
-    for (int q = 0; q < NF; q++) {
-      const float fp = (float)((double)f0[q] +
-                               ((double)h0.drift / 2.0) * ((double)(float)own_i - 81.0) / 81.0);  // cc:173
-      double sn, cs;
-      sincos(kTwoPiDt * (double)(fp + delta), &sn, &cs);
-      cd[q] = (float)cs; sd[q] = (float)sn; c[q] = 1.0f; s[q] = 0.0f;
-    }
-    load_chunk(0);
-    for (int ch = 0; ch < NCH; ch++) {
-      __syncthreads();
-      store_chunk();
-      __syncthreads();
-      load_chunk(min(ch + 1, NCH - 1));
-#pragma unroll
-      for (int k = 0; k < CH; k += 2) {
-        const float4 x4 = *reinterpret_cast<const float4 *>(&smp[row * K4F_ROWDW + 2 * k]);
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-          const float xx = half ? x4.z : x4.x, xy = half ? x4.w : x4.y;
-#pragma unroll
-          for (int q = 0; q < NF; q++) {
-            k4_mac<FAST>(inp[q], quad[q], xx, xy, c[q], s[q]);        // cc:206-207
-            k4_rot<FAST>(c[q], s[q], cd[q], sd[q]);                  // cc:193-195
-          }
-        }
-      }
-    }
-  }
-
-  if (mine) {
-#pragma unroll
-    for (int q = 0; q < NF; q++)
-      if (!(skip_mid && q == NF / 2))
-        p_out[(((long long)slot * NF + q) * UWSPR_NSYM + own_i) * 4 + tone] =
-            ieee_sqrtf(inp[q] * inp[q] + quad[q] * quad[q]);   // cc:211
-  }
-}
-
 // S0 of the schedule (cc:409-415: five lags 64 samples apart at one frequency), sample-major, for the slots
 // whose frequency does not depend on the symbol (their phasor table exists: dev_grp::nvalid bits 16..23; the
-// others are left to k4_group).  The four computed lags of a symbol read windows that overlap by three quarters
+// others are left to the flat kernel).  The four computed lags of a symbol read windows that overlap by three quarters
 // (lag q covers samples [64 q, 64 q + 256) of the row's 448), so the row is streamed ONCE in 14 chunks of 32
 // samples and every staged sample feeds each lag whose window it lies in, against phasor step k = a - 64 q of
 // the slot's table (LDS, broadcast: the tone is wavefront-uniform) -- no recurrence, no per-lag reload.  The
-// fifth lag is the first one symbol later (k4_group's wrap): a 163rd, virtual row per slot supplies it for
+// fifth lag is the first one symbol later: a 163rd, virtual row per slot supplies it for
 // symbol 161.  Rows are packed like k4_fpack's: 64 consecutive (slot, row) pairs per workgroup, four tone
 // wavefronts, at most two slots per workgroup.  Every accumulator still sees the reference's operation
 // sequence (cc:206-207); the table is the recurrence of cc:193-195, computed once per slot.
@@ -1024,7 +594,7 @@ __global__ __launch_bounds__(256, 4) void k4_lag0(   // 4 wavefronts per SIMD: <
   const bool hasB = sb < ROWS && slotA + 1 < nslots;
   const int slotB = hasB ? slotA + 1 : slotA;
   const dev_grp A = grps[slotA], Bg = grps[slotB];
-  // a slot is taken here only if it is live AND has its table (else k4_group's launch has it)
+  // a slot is taken here only if it is live AND has its table (else the flat kernel's launch has it)
   const int selA = (A.nvalid >> 16) & 0xff, selB = (Bg.nvalid >> 16) & 0xff;
   const bool doA = A.frame >= 0 && A.frame < nframes && selA != 0;
   const bool doB = hasB && Bg.frame >= 0 && Bg.frame < nframes && selB != 0;
@@ -1135,12 +705,15 @@ void launch_tonecorr_lag0(uwspr_ctx *c, const float *frames, int B, const dev_gr
                  nslots, (float *)p, (const float2 *)c->d_ptab);
 }
 
-// Packed form of the frequency stage: the (slot, symbol) pairs of the whole launch are flattened and a
-// workgroup takes 64 consecutive ones -- all 64 lanes of its four tone wavefronts work (k4_fstage's three
-// parts of 54 symbols leave ten lanes in 64 idle: a sixth of the stage's multiply-add instructions).  A workgroup
-// then spans at most two slots (162 > 64): two sets of hypothesis parameters, two phasor-table sets in LDS
-// (generated by lanes 0..39 of wavefront 0), each lane reading its own slot's.  Arithmetic per accumulator and
-// per phasor is k4_fstage's, i.e. the reference's sequence.  Fallbacks inside: a slot whose frequency depends on
+// Frequency stage (S1 / S4: the NF hypotheses of a candidate slot share frame, lag and drift model and differ only
+// in f0, cc:416-419, 449-452): every lane correlates its symbol window against all NF frequencies -- the window is
+// staged and read once for NF hypotheses.  When the per-symbol frequency does not depend on the symbol (drift == 0
+// or the nonlinear model: the usual case) the phasor sequence c[k], s[k] (cc:186-199) is the same for all symbols
+// of a (frequency, tone) -- the reference caches it via `fplast` for the same reason -- so lanes 0..39 of wavefront
+// 0 advance the recurrences (a recurrence step costs its wavefront six instruction slots however few lanes run it),
+// publish 32 steps at a time in LDS, and the other lanes only multiply-accumulate.  A workgroup spans at most two
+// slots (162 > 64): two sets of hypothesis parameters, two phasor-table sets in LDS, each lane reading its own
+// slot's.  Every accumulator and every phasor sees the reference's operation sequence.  Fallbacks inside: a slot whose frequency depends on
 // the symbol (drifting linear model) puts the whole workgroup on per-lane recurrences; the known middle frequency
 // is left out only when every live slot of the workgroup has it marked.
 #ifdef K4F_STAMPS   // diagnostic build only (tools/k4f_stamps.py): where a k4_fpack wavefront's cycles go
@@ -1369,298 +942,17 @@ void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_
                             int64_t nhyps, float4 *p) {
   if (nslots <= 0) return;
   prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
-  if (c->k4_fpack) {
-    const unsigned wgs = (unsigned)(((long long)nslots * UWSPR_NSYM + 63) / 64);
-    if (c->fast_now)
-      launch_timed(c, ps, (k4_fpack<5, K4F_CHUNK, true>), dim3(wgs), dim3(256), 0,
-                   (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p);
-    else
-      launch_timed(c, ps, (k4_fpack<5, K4F_CHUNK>), dim3(wgs), dim3(256), 0,
-                   (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p);
-    return;
-  }
+  const unsigned wgs = (unsigned)(((long long)nslots * UWSPR_NSYM + 63) / 64);
   if (c->fast_now)
-    launch_timed(c, ps, (k4_fstage<5, K4F_CHUNK, true>), dim3(3u * (unsigned)nslots), dim3(256), 0,
-                 (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p, c->k4f_onegen ? 1 : 0);
+    launch_timed(c, ps, (k4_fpack<5, K4F_CHUNK, true>), dim3(wgs), dim3(256), 0,
+                 (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p);
   else
-    launch_timed(c, ps, (k4_fstage<5, K4F_CHUNK>), dim3(3u * (unsigned)nslots), dim3(256), 0,
-                 (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p, c->k4f_onegen ? 1 : 0);
+    launch_timed(c, ps, (k4_fpack<5, K4F_CHUNK>), dim3(wgs), dim3(256), 0,
+                 (const float2 *)frames, c->fstride, c->np, B, hyps, nslots, (float *)p);
 }
 
 }  // namespace uwspr
 
-// ---------------------------------------------------------------------------
-// Grid form: the (freq, drift, lag) sweep around one centre per frame
-// (BASELINE configs[2]).  All hypotheses of a frame and symbol read the same
-// samples, and hypotheses that differ only in lag share their tone phasors, so:
-//  * a wavefront takes 16 consecutive (symbol, freq x drift combination) pairs of
-//    ONE frame (symbol-major order => at most a few distinct symbols per wave) and
-//    loads each needed symbol window [lagmin + 256 i, lagmax + 256 i + 256) ONCE,
-//    whole, into LDS with coalesced 8-byte loads (the n > 0 && n < np test of
-//    cc:205 is applied here: skipped samples become zeros, which leave inp/quad
-//    unchanged);
-//  * a lane owns one pair and one tone: one phasor recurrence, NL accumulator
-//    pairs (one per lag), reading sample k + (lag_l - lagmin) of its window;
-//  * after the window load the 256-sample walk touches no global memory at all.
-// Arithmetic per accumulator is the reference's sequence (cc:193-195, 206-207).
-namespace uwspr {
-
-struct grid_args {
-  int nf, ndrift, ncombo, nlag_total, lag_base;  // this launch covers lags lag_base..lag_base+NL-1
-  int wlen, wstride, wmax;                       // window length / LDS stride (samples), windows per wave
-  int dlag_min;                                  // min over ALL lag offsets of the launch block
-  int off[8];                                    // dlag[l] - dlag_min for the NL lags
-  int nvalid;                                    // lags in use (<= NL)
-  float df[32], ddrift[32];
-};
-
-constexpr int K4GR_WAVES = 4;
-
-template <int NL>
-__global__ __launch_bounds__(64 * K4GR_WAVES) void k4_grid(
-    const float2 *__restrict__ frames, int fstride, int np, int nframes,
-    const uwspr_candidate *__restrict__ centres, const int32_t *__restrict__ cframe,
-    grid_args ga, float cf, float *__restrict__ p_out) {
-  extern __shared__ __align__(16) float lds_dyn[];
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float2 *win = reinterpret_cast<float2 *>(lds_dyn) + (size_t)wv * ga.wmax * ga.wstride;
-
-  const int b = blockIdx.y;                      // centre index
-  const int npairs = UWSPR_NSYM * ga.ncombo;
-  const int nwv = blockDim.x >> 6;
-  const int q0 = (blockIdx.x * nwv + wv) * 16;
-  if (q0 >= npairs) return;  // wave-uniform
-  const int frame = cframe ? cframe[b] : b;     // several centres may share a frame
-  if (frame < 0 || frame >= nframes) return;    // dead centre: its hypotheses are marked skipped
-  const uwspr_candidate ce = centres[b];
-  const int i_first = q0 / ga.ncombo;
-  const int i_last = min(q0 + 15, npairs - 1) / ga.ncombo;
-  const int nwin = i_last - i_first + 1;  // <= ga.wmax by construction
-
-  // ---- load the symbol windows (whole) ------------------------------------
-  {
-    const float2 *fb = frames + (long long)frame * fstride;
-    const int n0 = ce.shift + ga.dlag_min + 256 * i_first;
-    const int tot = nwin * ga.wlen;
-    for (int e = lane; e < tot; e += 64) {
-      const int w = e / ga.wlen, r = e - w * ga.wlen;
-      const int n = n0 + 256 * w + r;
-      const bool inr = (n > 0) && (n < np);  // cc:205, sample 0 excluded
-      const float2 v = fb[min(max(n, 0), np - 1)];
-      win[w * ga.wstride + r] = inr ? v : make_float2(0.0f, 0.0f);
-    }
-  }
-  wave_lds_fence();
-
-  const int pr = lane >> 2;
-  const int tone = lane & 3;
-  const int q = q0 + pr;
-  const bool ok = q < npairs;
-  const int i = ok ? q / ga.ncombo : i_first;
-  const int cb = ok ? q - i * ga.ncombo : 0;
-  const int fi = cb / ga.ndrift, di = cb - fi * ga.ndrift;
-
-  // ---- this lane's tone phasor step (binary64 angle, cc:164-189) -----------
-  float cd, sd;
-  {
-    const float f0 = ce.freq + ga.df[fi];  // cc:164
-    float fp;
-    if (ce.m_type == UWSPR_LINEAR) {
-      const float drift = ce.m_linear.drift + ga.ddrift[di];
-      fp = (float)((double)f0 + ((double)drift / 2.0) * ((double)(float)i - 81.0) / 81.0);
-    } else if (ce.m_type == 2) {
-      fp = f0 + ce.m_linear.drift;  // internal: nonlinear centre with its SLM constant precomputed
-    } else {
-      // slmFrequencyDrift(m_nl, cf, t = 0), lib/slm.cc:36-73
-      const double q1 = (double)ce.m_nonlinear.p1, q2 = (double)ce.m_nonlinear.p2;
-      const double V1 = ce.m_nonlinear.V1, V2 = ce.m_nonlinear.V2;
-      const float sign = (float)(((q1 * V1 + q2 * V2) > 0) * 2 - 1);
-      const double num = fabs(V1 * q1 + V2 * q2), den = sqrt(q1 * q1 + q2 * q2);
-      const float slmc = den == 0 ? 0.0f : (float)((double)(-sign) * num / den * (double)cf / (double)1500.0f);
-      fp = f0 + slmc;
-    }
-    const float delta = ((float)tone - 1.5f) * 1.46484375f;
-    double sn, cs;
-    sincos(kTwoPiDt * (double)(fp + delta), &sn, &cs);
-    cd = (float)cs;
-    sd = (float)sn;
-  }
-
-  float c = 1.0f, s = 0.0f;
-  float inp[NL], quad[NL];
-#pragma unroll
-  for (int l = 0; l < NL; l++) { inp[l] = 0.0f; quad[l] = 0.0f; }
-
-  // dword offsets of the NL lag columns inside this wave's windows (integers, so the reads stay
-  // ds_read with compile-time column offsets); the reads of step k+1 are issued before the
-  // arithmetic of step k and pinned there
-  const float *winf = reinterpret_cast<const float *>(win);
-  int ao[NL];
-#pragma unroll
-  for (int l = 0; l < NL; l++) ao[l] = 2 * ((i - i_first) * ga.wstride + ga.off[l]);
-  for (int k0 = 0; k0 < 256; k0 += 16) {
-    float2 xc[NL], xn[NL];
-#pragma unroll
-    for (int l = 0; l < NL; l++) { xc[l] = *reinterpret_cast<const float2 *>(&winf[ao[l]]); xn[l] = xc[l]; }
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      if (k < 15) {
-#pragma unroll
-        for (int l = 0; l < NL; l++) xn[l] = *reinterpret_cast<const float2 *>(&winf[ao[l] + 2 * (k + 1)]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int l = 0; l < NL; l++) {
-        inp[l] = (inp[l] + xc[l].x * c) + xc[l].y * s;     // cc:206
-        quad[l] = (quad[l] - xc[l].x * s) + xc[l].y * c;   // cc:207
-      }
-      const float nc = c * cd - s * sd;            // cc:193-195
-      const float ns = c * sd + s * cd;
-      c = nc; s = ns;
-#pragma unroll
-      for (int l = 0; l < NL; l++) xc[l] = xn[l];
-    }
-#pragma unroll
-    for (int l = 0; l < NL; l++) ao[l] += 32;      // next 16 samples
-  }
-
-  if (ok) {
-#pragma unroll
-    for (int l = 0; l < NL; l++) {
-      if (l < ga.nvalid) {
-        const long long hyp = ((long long)b * ga.ncombo + cb) * ga.nlag_total + ga.lag_base + l;
-        p_out[(hyp * UWSPR_NSYM + i) * 4 + tone] = ieee_sqrtf(inp[l] * inp[l] + quad[l] * quad[l]);  // cc:211
-      }
-    }
-  }
-}
-
-// flat list of the grid's hypotheses (for the fold, and as the definition of the order)
-__global__ void k_grid_hyps(const uwspr_candidate *__restrict__ centres, grid_args ga, int nlag,
-                            const int *__restrict__ dlag, float cf, dev_hyp *__restrict__ out, int B) {
-  const long long h = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long per = (long long)ga.ncombo * nlag;
-  if (h >= per * B) return;
-  const int b = (int)(h / per);
-  const int r = (int)(h - (long long)b * per);
-  const int cb = r / nlag, l = r - cb * nlag;
-  const int fi = cb / ga.ndrift, di = cb - fi * ga.ndrift;
-  const uwspr_candidate ce = centres[b];
-  dev_hyp d;
-  d.frame = b; d.lag = ce.shift + dlag[l]; d.f0 = ce.freq + ga.df[fi]; d.m_type = ce.m_type;
-  d.drift = (ce.m_type == UWSPR_LINEAR) ? ce.m_linear.drift + ga.ddrift[di] : 0.0f;
-  d.slmc = 0.0f;
-  if (ce.m_type == UWSPR_NONLINEAR) {  // slmFrequencyDrift(m_nl, cf, t = 0), lib/slm.cc:36-73
-    const double q1 = (double)ce.m_nonlinear.p1, q2 = (double)ce.m_nonlinear.p2;
-    const double V1 = ce.m_nonlinear.V1, V2 = ce.m_nonlinear.V2;
-    const float sign = (float)(((q1 * V1 + q2 * V2) > 0) * 2 - 1);
-    const double num = fabs(V1 * q1 + V2 * q2), den = sqrt(q1 * q1 + q2 * q2);
-    d.slmc = den == 0 ? 0.0f : (float)((double)(-sign) * num / den * (double)cf / (double)1500.0f);
-  }
-  out[h] = d;
-}
-
-template <int NL>
-static void launch_grid_t(uwspr_ctx *c, prof_scope &ps, const float2 *fr, int nframes, int ncentres,
-                          const uwspr_candidate *centres, const int32_t *cframe, const grid_args &ga,
-                          int wpw, float *po) {
-  const int npairs = UWSPR_NSYM * ga.ncombo;
-  const int waves = (npairs + 15) / 16;
-  dim3 grid((waves + wpw - 1) / wpw, ncentres);
-  const size_t lds = (size_t)wpw * ga.wmax * ga.wstride * sizeof(float2);
-  launch_timed(c, ps, k4_grid<NL>, grid, dim3(64 * wpw), lds, fr, c->fstride, c->np, nframes, centres,
-                     cframe, ga, (float)c->p.cf, po);
-}
-
-// waves per workgroup such that the symbol windows fit 64 KB of LDS (0 = does not fit)
-static int grid_waves_per_wg(const grid_args &ga) {
-  for (int w = K4GR_WAVES; w >= 1; w >>= 1)
-    if ((size_t)w * ga.wmax * ga.wstride * sizeof(float2) <= 64 * 1024) return w;
-  return 0;
-}
-
-// One lag block (<= 8 lags) of a grid around `ncentres` centres; false = does not fit LDS.
-bool launch_grid_block(uwspr_ctx *c, const float *frames, int nframes, int ncentres,
-                       const uwspr_candidate *centres, const int32_t *cframe, grid_args &ga,
-                       const int *dlag, int nv, int64_t units, float4 *p) {
-  int lo = dlag[0], hi = dlag[0];
-  for (int l = 1; l < nv; l++) { lo = std::min(lo, dlag[l]); hi = std::max(hi, dlag[l]); }
-  ga.nvalid = nv; ga.dlag_min = lo;
-  ga.wlen = 256 + (hi - lo);
-  ga.wstride = ga.wlen | 1;  // odd stride: windows of a wave start on different bank pairs
-  for (int l = 0; l < 8; l++) ga.off[l] = dlag[std::min(l, nv - 1)] - lo;
-  const int wpw = grid_waves_per_wg(ga);
-  if (wpw == 0) return false;
-  prof_scope ps(c, UWSPR_K_TONECORR, units, true);
-  const float2 *fr = (const float2 *)frames;
-  float *po = (float *)p;
-  const int NL = nv <= 1 ? 1 : nv <= 2 ? 2 : nv <= 4 ? 4 : nv <= 5 ? 5 : nv <= 6 ? 6 : 8;
-  switch (NL) {
-    case 1: launch_grid_t<1>(c, ps, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
-    case 2: launch_grid_t<2>(c, ps, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
-    case 4: launch_grid_t<4>(c, ps, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
-    case 5: launch_grid_t<5>(c, ps, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
-    case 6: launch_grid_t<6>(c, ps, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
-    default: launch_grid_t<8>(c, ps, fr, nframes, ncentres, centres, cframe, ga, wpw, po); break;
-  }
-  return true;
-}
-
-static void grid_args_init(grid_args &ga, int nf, const float *df, int ndrift, const float *ddrift, int nlag) {
-  memset(&ga, 0, sizeof(ga));
-  ga.nf = nf; ga.ndrift = ndrift; ga.ncombo = nf * ndrift; ga.nlag_total = nlag;
-  for (int i = 0; i < nf; i++) ga.df[i] = df[i];
-  for (int i = 0; i < ndrift; i++) ga.ddrift[i] = ddrift[i];
-  ga.wmax = std::min(16, (15 + ga.ncombo - 1) / ga.ncombo + 1);
-}
-
-// The schedule's frequency / drift stages (S1, S4: 5 frequencies; S2: 2 drifts) around one
-// centre per candidate slot, all at a single lag: one grid block, hypotheses slot*ncombo + q.
-bool launch_tonecorr_stage_grid(uwspr_ctx *c, const float *frames, int nframes, int nslots,
-                                const uwspr_candidate *centres, const int32_t *cframe, int nf,
-                                const float *df, int ndrift, const float *ddrift, float4 *p) {
-  grid_args ga;
-  grid_args_init(ga, nf, df, ndrift, ddrift, 1);
-  const int zero = 0;
-  ga.lag_base = 0;
-  return launch_grid_block(c, frames, nframes, nslots, centres, cframe, ga, &zero, 1,
-                           (int64_t)nslots * nf * ndrift, p);
-}
-
-// returns false when the grid does not fit the on-chip window scheme (caller falls back)
-bool launch_tonecorr_grid(uwspr_ctx *c, const float *frames, int B, const uwspr_candidate *centres,
-                          int nf, const float *df, int ndrift, const float *ddrift, int nlag,
-                          const int *dlag_host, const int *dlag_dev, dev_hyp *hyps, float4 *p) {
-  if (nf < 1 || nf > 32 || ndrift < 1 || ndrift > 32 || nlag < 1) return false;
-  grid_args ga;
-  grid_args_init(ga, nf, df, ndrift, ddrift, nlag);
-  {
-    prof_scope ps(c, UWSPR_K_SCHED, (int64_t)B * ga.ncombo * nlag);
-    const long long H = (long long)B * ga.ncombo * nlag;
-    hipLaunchKernelGGL(k_grid_hyps, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, c->stream, centres, ga,
-                       nlag, dlag_dev, (float)c->p.cf, hyps, B);
-  }
-  // lag blocks of up to 8; each block has its own window span
-  for (int base = 0; base < nlag; base += 8) {
-    const int nv = std::min(8, nlag - base);
-    ga.lag_base = base;
-    if (!launch_grid_block(c, frames, B, B, centres, nullptr, ga, dlag_host + base, nv,
-                           (int64_t)B * ga.ncombo * nv, p))
-      return false;
-  }
-  return true;
-}
-
-}  // namespace uwspr
-
-#ifdef K4_STAMPS
-extern "C" int uwspr_debug_k4_stamps(unsigned long long *out, int nwaves) {
-  if (nwaves > uwspr::K4_STAMP_WAVES) nwaves = uwspr::K4_STAMP_WAVES;
-  hipDeviceSynchronize();
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(uwspr::g_k4_stamps), (size_t)nwaves * 32);
-}
-#endif
 #ifdef K4F_STAMPS
 extern "C" int uwspr_debug_k4f_stamps(unsigned long long *out, int nwaves) {
   if (nwaves > uwspr::K4F_STAMP_WAVES) nwaves = uwspr::K4F_STAMP_WAVES;

@@ -7,8 +7,6 @@
 //   soft symbols   cc:216-224 and the mode-2 epilogue cc:240-254
 //   schedule       sync_and_demodulate_impl::demodulate cc:403-482 (S0..S5)
 //   best-of rule   cc:227-231 (strict >, first wins; -1e30 / 0 / 0.0 defaults)
-#include <stdlib.h>
-
 #include "uwspr_internal.h"
 
 #pragma clang fp contract(off)
@@ -205,101 +203,8 @@ __device__ __forceinline__ float fold_wave(const dev_hyp *__restrict__ hyps,
   return sync;
 }
 
-// The same fold with NO LDS at all: every lane keeps its three symbols' terms in registers and the
-// order-sensitive running sums walk them with v_readlane (the symbol index is wave-uniform, so the
-// lane select is a constant); all 64 lanes carry the same sums.  About twice the instructions of the
-// LDS form per fold (a readlane per term) -- but the schedule's fold kernels run beside the tone
-// correlation launches of the other batches, which hold most of every CU's LDS: the 26 KB workgroups
-// of the LDS form waited for LDS for 40-65 us where the fold itself takes 6 (round-2 overlap profile);
-// a workgroup that needs registers only is placed at once.
-__device__ __forceinline__ float rl_f(float v, int l) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-__device__ __forceinline__ double rl_d(double v, int l) {
-  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
-  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-template <bool SOFT>
-__device__ __forceinline__ float fold_wave_rl(const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p,
-                                              int h, float symfac, uint8_t *__restrict__ symbols,
-                                              const float4 *__restrict__ prow = nullptr) {
-  const int lane = threadIdx.x & 63;
-  if (hyps[h].frame < 0 && !prow) {
-    if (SOFT)
-      for (int i = lane; i < UWSPR_NSYM; i += 64) symbols[(size_t)h * UWSPR_NSYM + i] = 0;
-    return -1e30f;
-  }
-  const float4 *src = prow ? prow : p + (size_t)h * UWSPR_NSYM;
-  float4 P[3];
-  float cm[3], fs[3];
-  double q0[3], q1[3];
-#pragma unroll
-  for (int r = 0; r < 3; r++) {
-    const int i = lane + 64 * r;
-    P[r] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); cm[r] = 0.0f; fs[r] = 0.0f; q0[r] = 0.0; q1[r] = 0.0;
-    if (i < UWSPR_NSYM) {
-      P[r] = src[i];
-      const bool bit = pr3_rt(i);
-      const float cmet = (P[r].y + P[r].w) - (P[r].x + P[r].z);   // cc:214
-      cm[r] = bit ? cmet : -cmet;                                  // ss -/+ cmet == ss + (-/+cmet)
-      fs[r] = bit ? P[r].w - P[r].y : P[r].z - P[r].x;             // cc:219,222
-      if (SOFT) {
-        q0[r] = (double)fs[r] / 162.0;                             // cc:243
-        q1[r] = (double)(fs[r] * fs[r]) / 162.0;                   // cc:244
-      }
-    }
-  }
-  float totp = 0.0f, ss = 0.0f, fsum = 0.0f, f2sum = 0.0f;
-#pragma unroll
-  for (int r = 0; r < 3; r++) {
-#pragma unroll
-    for (int l = 0; l < 64; l++) {
-      if (64 * r + l >= UWSPR_NSYM) continue;
-      // cc:213: totp = (((totp+p0)+p1)+p2)+p3; cc:215: ss
-      totp = totp + rl_f(P[r].x, l); totp = totp + rl_f(P[r].y, l);
-      totp = totp + rl_f(P[r].z, l); totp = totp + rl_f(P[r].w, l);
-      ss = ss + rl_f(cm[r], l);
-      if (SOFT) {
-        fsum = (float)((double)fsum + rl_d(q0[r], l));
-        f2sum = (float)((double)f2sum + rl_d(q1[r], l));
-      }
-    }
-  }
-  const float sync = ieee_divf(ss, totp);  // cc:226
-  if (SOFT) {
-    const float fac = ieee_sqrtf(f2sum - fsum * fsum);  // cc:246
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const int i = lane + 64 * r;
-      if (i < UWSPR_NSYM) {
-        float v = ieee_divf(symfac * fs[r], fac);  // cc:248
-        if (v > 127.0f) v = 127.0f;
-        if (v < -128.0f) v = -128.0f;
-        v = v + 128.0f;
-        symbols[(size_t)h * UWSPR_NSYM + i] = (v != v) ? (uint8_t)0 : (uint8_t)(int)v;
-      }
-    }
-  }
-  return sync;
-}
-
 // pwin / per_slot (stage 5 of the schedule, else null): hypothesis h belongs to slot h / per_slot; one marked
 // known (frame <= -2) repeats the stage-4 winner and is folded from pwin[slot] (its magnitudes, carried)
-template <bool SOFT>
-__global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave_rl(
-    const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p, int H, float symfac,
-    float *__restrict__ sync, uint8_t *__restrict__ symbols, const float4 *__restrict__ pwin, int per_slot) {
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = blockIdx.x * K5W_WAVES + wv;
-  if (h >= H) return;  // wave-uniform
-  const float4 *prow = (pwin && hyps[h].frame <= -2) ? pwin + (size_t)(h / per_slot) * UWSPR_NSYM : nullptr;
-  const float s = fold_wave_rl<SOFT>(hyps, p, h, symfac, symbols, prow);
-  if ((threadIdx.x & 63) == 0) sync[h] = s;
-}
-
 template <bool SOFT>
 __global__ __launch_bounds__(64 * K5W_WAVES) void k5_fold_wave(
     const dev_hyp *__restrict__ hyps, const float4 *__restrict__ p, int H, float symfac,
@@ -319,22 +224,17 @@ void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, floa
                  uint8_t *symbols, const float4 *pwin, int per_slot) {
   if (H <= 0) return;
   prof_scope ps(c, UWSPR_K_FOLD, H);
-  // lanes form from 32768 hypotheses up (UWSPR_K5_LANES=0/1 forces one or the other).  The schedule's stage 5
-  // (4352 tries for 256 slots) stays on the wave form: through the lanes form (UWSPR_K5_S5_LANES=1) it is 68
-  // wavefronts and a twentieth of the instructions, but each walks 162 symbols serially -- 169 us instead of
-  // 64 on the lane's critical path, -4 % frames/s under three streams (round-3 A/B)
-  static const int forced = getenv("UWSPR_K5_LANES") ? atoi(getenv("UWSPR_K5_LANES")) : -1;
-  const bool lanes_form = forced >= 0 ? forced != 0 : (H >= 32768 || (pwin != nullptr && c->k5_s5_lanes));
+  // lanes form from 32768 hypotheses up (option "k5_lanes" = 0 / 1 forces one or the other).  The schedule's stage 5
+  // (4352 tries for 256 slots) stays on the wave form: through the lanes form it is 68 wavefronts and a twentieth of
+  // the instructions, but each walks 162 symbols serially -- 169 us instead of 64 on the lane's critical path,
+  // -4 % frames/s under three streams (round-3 A/B)
+  const int forced = c->opt[UWSPR_OPT_K5_LANES];
+  const bool lanes_form = forced >= 0 ? forced != 0 : H >= 32768;
   if (per_slot < 1) per_slot = 1;
   if (!lanes_form) {
     dim3 g((H + K5W_WAVES - 1) / K5W_WAVES), b(64 * K5W_WAVES);
-    if (c->use_k5_lds) {
-      if (symbols) hipLaunchKernelGGL(k5_fold_wave<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols, pwin, per_slot);
-      else hipLaunchKernelGGL(k5_fold_wave<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols, pwin, per_slot);
-    } else {
-      if (symbols) hipLaunchKernelGGL(k5_fold_wave_rl<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols, pwin, per_slot);
-      else hipLaunchKernelGGL(k5_fold_wave_rl<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols, pwin, per_slot);
-    }
+    if (symbols) hipLaunchKernelGGL(k5_fold_wave<true>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols, pwin, per_slot);
+    else hipLaunchKernelGGL(k5_fold_wave<false>, g, b, 0, c->stream, hyps, p, H, 50.0f, sync, symbols, pwin, per_slot);
   } else {
     hipLaunchKernelGGL(k5_fold, dim3((H + 63) / 64), dim3(64), 0, c->stream, hyps, p, H, 50.0f,
                        sync, symbols, pwin, per_slot);
@@ -702,9 +602,7 @@ __device__ __forceinline__ float fold_wave_fast(const dev_hyp *__restrict__ hyps
   return ieee_divf(wave_sum(sm), wave_sum(tp));
 }
 
-// LDS: the folds go through LDS (fold_wave) or registers (fold_wave_rl).  ONEWAVE: one wavefront folds the
-// slot's hypotheses one after the other (5 KB of LDS per workgroup instead of 26 KB).
-template <int STAGE, bool LDS, bool ONEWAVE, bool FAST = false>
+template <int STAGE, bool FAST = false>
 __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__restrict__ hin,
                              const float4 *__restrict__ p, float *__restrict__ sync,
                              dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
@@ -713,19 +611,19 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
                              dev_row *__restrict__ rows) {
   UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   constexpr int NIN = STAGE == 3 ? 2 : 5;
-  __shared__ k5_wave_lds L[LDS ? (ONEWAVE ? 1 : NIN) : 1];
+  __shared__ k5_wave_lds L[FAST ? 1 : NIN];
   __shared__ float sy[NIN];
   __shared__ int s_wsrc;
   const int slot = blockIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int q = ONEWAVE ? 0 : wv; q < (ONEWAVE ? NIN : wv + 1); q++) {
+  {
+    const int q = wv;
     const int h = slot * NIN + q;
     // a hypothesis marked known (frame <= -2) repeats the previous winner: its metric is in the state
     float s;
     if (hin[h].frame <= -2) s = state[slot].csync;
     else if (FAST) s = fold_wave_fast(hin, p, h);
-    else if (LDS) s = fold_wave<false>(hin, p, h, 50.0f, nullptr, L[(LDS && !ONEWAVE) ? q : 0], nullptr);
-    else s = fold_wave_rl<false>(hin, p, h, 50.0f, nullptr);
+    else s = fold_wave<false>(hin, p, h, 50.0f, nullptr, L[FAST ? 0 : q], nullptr);
     if ((threadIdx.x & 63) == 0) { sy[q] = s; sync[h] = s; }
   }
   __syncthreads();
@@ -880,38 +778,21 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots, int njig) {
                        c->d_cent, c->d_cent_frame, nslots, reuse, njig, (float4 *)c->d_pwin,
                        c->use_ptab ? c->d_ptab : nullptr, c->d_rows);
   };
-  const bool one = c->k5_onewave;
   if (c->fast_now) {
     switch (stage) {
-      case 1: go(k5_fold_step<1, false, false, true>, 320); break;
-      case 2: go(k5_fold_step<2, false, false, true>, 320); break;
-      case 3: go(k5_fold_step<3, false, false, true>, 128); break;
-      case 4: go(k5_fold_step<4, false, false, true>, 320); break;
-      default: go(k5_fold_step<5, false, false, true>, 320); break;
-    }
-  } else if (c->use_k5_lds && !one) {
-    switch (stage) {
-      case 1: go(k5_fold_step<1, true, false>, 320); break;
-      case 2: go(k5_fold_step<2, true, false>, 320); break;
-      case 3: go(k5_fold_step<3, true, false>, 128); break;
-      case 4: go(k5_fold_step<4, true, false>, 320); break;
-      default: go(k5_fold_step<5, true, false>, 320); break;
-    }
-  } else if (c->use_k5_lds) {
-    switch (stage) {
-      case 1: go(k5_fold_step<1, true, true>, 64); break;
-      case 2: go(k5_fold_step<2, true, true>, 64); break;
-      case 3: go(k5_fold_step<3, true, true>, 64); break;
-      case 4: go(k5_fold_step<4, true, true>, 64); break;
-      default: go(k5_fold_step<5, true, true>, 64); break;
+      case 1: go(k5_fold_step<1, true>, 320); break;
+      case 2: go(k5_fold_step<2, true>, 320); break;
+      case 3: go(k5_fold_step<3, true>, 128); break;
+      case 4: go(k5_fold_step<4, true>, 320); break;
+      default: go(k5_fold_step<5, true>, 320); break;
     }
   } else {
     switch (stage) {
-      case 1: go(k5_fold_step<1, false, false>, 320); break;
-      case 2: go(k5_fold_step<2, false, false>, 320); break;
-      case 3: go(k5_fold_step<3, false, false>, 128); break;
-      case 4: go(k5_fold_step<4, false, false>, 320); break;
-      default: go(k5_fold_step<5, false, false>, 320); break;
+      case 1: go(k5_fold_step<1>, 320); break;
+      case 2: go(k5_fold_step<2>, 320); break;
+      case 3: go(k5_fold_step<3>, 128); break;
+      case 4: go(k5_fold_step<4>, 320); break;
+      default: go(k5_fold_step<5>, 320); break;
     }
   }
 }

@@ -393,9 +393,8 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
   if (q->o.batch_frames <= 0) q->o.batch_frames = 256;
   if (q->o.max_per_frame <= 0) q->o.max_per_frame = 1;
   if (q->o.lanes <= 0) q->o.lanes = 9;   // three streams + six spares (take_lane)
-  if (const char *e = getenv("UWSPR_PIPE_LANES")) { if (atoi(e) > 0) q->o.lanes = atoi(e); }   // (probes)
   if (q->o.lanes > 12) q->o.lanes = 12;
-  q->spare_after = getenv("UWSPR_PIPE_SPARE_AFTER_US") ? 1e-6 * atof(getenv("UWSPR_PIPE_SPARE_AFTER_US")) : kSpareAfter;
+  q->spare_after = q->o.spare_after_us > 0 ? 1e-6 * (double)q->o.spare_after_us : kSpareAfter;
   if (q->o.hop <= 0) q->o.hop = p->fl;
   if (q->o.hop > p->fl) return pfail(q, UWSPR_ERR_ARG, "hop=%d > fl=%d", q->o.hop, p->fl);
   q->per = q->o.max_per_frame < p->maxfreqs ? q->o.max_per_frame : p->maxfreqs;
@@ -418,10 +417,10 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
     }
     // schedule form: with three or more batches in flight the staged launches leave room for the other
     // lanes' kernels and win (861 k against 773 k decoded frames/s at 3 lanes); alone or in pairs the fused
-    // kernel does (tools/pipe_lanes_probe.py).  UWSPR_SCHED_FUSED in the environment still decides when set.
-    if (q->o.sched_form == 1) L.ctx->use_fused = true;
-    else if (q->o.sched_form == 2) L.ctx->use_fused = false;
-    else if (!getenv("UWSPR_SCHED_FUSED")) L.ctx->use_fused = q->o.lanes < kPipeStreams;
+    // kernel does (tools/pipe_lanes_probe.py).  A "sched" option in UWSPR_OPTIONS still decides when set.
+    if (q->o.sched_form == 1) (void)uwspr_set_option(L.ctx, "sched", 1);
+    else if (q->o.sched_form == 2) (void)uwspr_set_option(L.ctx, "sched", 0);
+    else if (!L.ctx->opt_set[UWSPR_OPT_SCHED]) (void)uwspr_set_option(L.ctx, "sched", q->o.lanes < kPipeStreams ? 1 : 0);
     PHIP(q, hipMalloc((void **)&L.d_cands, (size_t)Bm * p->maxfreqs * sizeof(uwspr_candidate)));
     PHIP(q, hipMalloc((void **)&L.d_npk, (size_t)Bm * sizeof(int32_t)));
     PHIP(q, hipMalloc((void **)&L.d_out, (size_t)Bm * per * sizeof(uwspr_demod_out)));
@@ -445,8 +444,7 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
   }
   if (q->o.host_threads <= 0) q->o.host_threads = host_cpu_share() > 3 ? host_cpu_share() - 2 : 1;
   q->pool = &host_pool::shared();   // the process-wide pool; this pipe's jobs use host_threads of it
-  int ncoords = (int)q->lanes.size();
-  if (const char *e = getenv("UWSPR_PIPE_COORDS")) { if (atoi(e) >= 1 && atoi(e) < ncoords) ncoords = atoi(e); }
+  const int ncoords = (int)q->lanes.size();
   for (int k = 0; k < ncoords; k++) q->coords.emplace_back(coordinator, q);
   return UWSPR_OK;
 }

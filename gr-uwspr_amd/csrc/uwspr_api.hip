@@ -17,7 +17,7 @@ namespace uwspr {
 int coarse_configure(const fdr_consts &f);
 size_t coarse_lds_bytes(const fdr_consts &f);
 int coarse_seq_words();
-size_t coarse_plan(fdr_consts &f);
+size_t coarse_plan(fdr_consts &f, int pitch_opt, int tile_opt);
 uint32_t coarse_seq_entry(const fdr_consts &f, int k, int off);
 }  // namespace uwspr
 
@@ -83,6 +83,83 @@ static float slm_frequency_drift(double V1, double V2, int p1, int p2, float cf,
   return (float)((double)(-sign) * num / den * (double)cf / (double)cs);
 }
 
+// ---------------------------------------------------------------- options
+// Every switch of the implementation is an option of the context: set by uwspr_set_option, or -- for experiments and
+// for the ones that shape the context when it is created (the "k1_" / "k3_" ones) -- listed in the one environment
+// variable UWSPR_OPTIONS="name=value,name=value".  Nothing else in the library reads the environment.
+static const struct { const char *name; int dflt; } kOptions[UWSPR_NOPT] = {
+    {"sched", 1},            // 1: fused kernel k6_sched; 0: staged launches
+    {"stage_kernels", 1},    // staged form: 0 flat kernel everywhere (the reference form), 1 packed / ring kernels, 2 rows form
+    {"reuse", 1},            // the hypothesis that repeats the previous stage's winner is not correlated again
+    {"phasor_tables", 1},    // lag stages read their phasors from per-slot tables
+    {"fast_search", 0},      // stages S0..S4 with fused multiply-adds and shuffle-tree sums (NOT the reference's arithmetic)
+    {"rows_mask", 31},       // stage_kernels = 2: bit per stage kind S0,S1,S3,S4,S5 that takes the rows form
+    {"k4_t", 0},             // flat kernel: tones per lane (0: by size)
+    {"k5_lanes", -1},        // fold: -1 by size, 0 wave form, 1 lanes form
+    {"k1_rows", 0},          // spectrogram: rows per wavefront walk (0: default)
+    {"k3_tile", -1},         // coarse search: tile form (-1: by size)
+    {"k3_pitch", 0},         // coarse search: tile row pitch (0: default)
+    {"sched_stamps", 0},     // diagnostics: phase times of the fused kernel (uwspr_debug_sched_stamps)
+    {"sched_grid", 0},       // fused kernel: workgroups (0: one per CU)
+    {"dist_force_comm", 0},  // tests: a one-rank communicator is really created
+};
+
+static void refresh_options(uwspr_ctx *c) {
+  c->use_fused = c->opt[UWSPR_OPT_SCHED] != 0;
+  c->use_stage_kernels = c->opt[UWSPR_OPT_STAGE_KERNELS] != 0;
+  c->reuse_centre = c->opt[UWSPR_OPT_REUSE] != 0;
+  c->use_ptab = c->opt[UWSPR_OPT_PHASOR_TABLES] != 0;
+  c->fast_search = c->opt[UWSPR_OPT_FAST_SEARCH] != 0;
+  if (c->fast_search) c->use_fused = false;   // the fast variant exists for the staged launches only
+  c->sched_grid = c->opt[UWSPR_OPT_SCHED_GRID];
+}
+
+static int option_index(const char *name) {
+  if (!name) return -1;
+  for (int i = 0; i < UWSPR_NOPT; i++)
+    if (!strcmp(name, kOptions[i].name)) return i;
+  return -1;
+}
+
+extern "C" int uwspr_set_option(uwspr_ctx *c, const char *name, int value) {
+  if (!c) return UWSPR_ERR_ARG;
+  const int i = option_index(name);
+  if (i < 0) return fail(c, UWSPR_ERR_ARG, "unknown option '%s'", name ? name : "(null)");
+  if (i == UWSPR_OPT_K1_ROWS || i == UWSPR_OPT_K3_TILE || i == UWSPR_OPT_K3_PITCH)
+    return fail(c, UWSPR_ERR_ARG, "option '%s' shapes the context when it is created: UWSPR_OPTIONS=%s=%d", name, name, value);
+  c->opt[i] = value; c->opt_set[i] = true;
+  refresh_options(c);
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_get_option(uwspr_ctx *c, const char *name, int *value) {
+  if (!c || !value) return UWSPR_ERR_ARG;
+  const int i = option_index(name);
+  if (i < 0) return fail(c, UWSPR_ERR_ARG, "unknown option '%s'", name ? name : "(null)");
+  *value = c->opt[i];
+  return UWSPR_OK;
+}
+
+// UWSPR_OPTIONS="name=value,..."; unknown names are an error of the context being created (a typo must not pass silently)
+static int options_from_environment(uwspr_ctx *c) {
+  for (int i = 0; i < UWSPR_NOPT; i++) { c->opt[i] = kOptions[i].dflt; c->opt_set[i] = false; }
+  const char *e = getenv("UWSPR_OPTIONS");
+  if (e) {
+    char buf[512];
+    strncpy(buf, e, sizeof(buf) - 1); buf[sizeof(buf) - 1] = 0;
+    for (char *tok = strtok(buf, ", "); tok; tok = strtok(nullptr, ", ")) {
+      char *eq = strchr(tok, '=');
+      if (!eq) return fail(c, UWSPR_ERR_ARG, "UWSPR_OPTIONS: '%s' is not name=value", tok);
+      *eq = 0;
+      const int i = option_index(tok);
+      if (i < 0) return fail(c, UWSPR_ERR_ARG, "UWSPR_OPTIONS: unknown option '%s'", tok);
+      c->opt[i] = atoi(eq + 1); c->opt_set[i] = true;
+    }
+  }
+  refresh_options(c);
+  return UWSPR_OK;
+}
+
 // ------------------------------------------------------------- ctx create
 extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **out) {
   if (!p || !out) return UWSPR_ERR_ARG;
@@ -101,55 +178,31 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->grid_cap = 0; c->cap_grid_bytes = 0; c->d_syncgrid = nullptr;
   c->cap_hyps = 0; c->d_hyps = nullptr; c->cap_grps = 0; c->d_grps = nullptr;
   c->cap_rows = 0; c->d_rows = nullptr;
-  c->use_rows = !(getenv("UWSPR_K4_ROWS") && atoi(getenv("UWSPR_K4_ROWS")) == 0);
-  {   // wavefronts per tone of a rows workgroup, per stage kind S0,S1,S3,S4,S5 (UWSPR_K4_ROWS_HS="1,1,1,1,2": experiments)
-    static const int dflt[5] = {1, 1, 1, 1, 2};
+  {   // wavefronts per tone of a rows workgroup, per stage kind S0,S1,S3,S4,S5
+    static const int dflt[5] = {2, 2, 2, 2, 2};
     for (int k = 0; k < 5; k++) c->rows_hs[k] = dflt[k];
-    if (const char *e = getenv("UWSPR_K4_ROWS_HS")) {
-      int v[5];
-      if (sscanf(e, "%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4]) == 5)
-        for (int k = 0; k < 5; k++) if (v[k] == 1 || v[k] == 2 || (k == 4 && v[k] == 4)) c->rows_hs[k] = v[k];
-    }
   }
   c->cap_cent = 0; c->d_cent = nullptr; c->d_cent_frame = nullptr; c->cap_abi_hyps = 0; c->d_abi_hyps = nullptr;
   c->cap_p = 0; c->d_p = nullptr; c->cap_sync = 0; c->d_sync = nullptr;
   c->cap_sym = 0; c->d_sym = nullptr; c->cap_state = 0; c->d_state = nullptr;
   c->cap_dout = 0; c->d_dout = nullptr; c->prof_mask = 0;
   c->cur_cands = nullptr; c->cur_npk = nullptr; c->cur_dout = nullptr; c->last_per_frame = 0;
-  // lag sweeps of the schedule share their tone phasors (k4_group); UWSPR_K4_GROUPS=0 falls
-  // back to one lane-set per hypothesis (k4_tonecorr) -- both are parity-tested
-  c->use_lag_groups = !(getenv("UWSPR_K4_GROUPS") && atoi(getenv("UWSPR_K4_GROUPS")) == 0);
-  c->use_lag_ring = !(getenv("UWSPR_K4_RING") && atoi(getenv("UWSPR_K4_RING")) == 0);
-  c->use_fstage = !(getenv("UWSPR_K4_FSTAGE") && atoi(getenv("UWSPR_K4_FSTAGE")) == 0);
-  c->reuse_centre = !(getenv("UWSPR_K4_REUSE") && atoi(getenv("UWSPR_K4_REUSE")) == 0);
-  c->use_k5_lds = !(getenv("UWSPR_K5_LDS") && atoi(getenv("UWSPR_K5_LDS")) == 0);
-  c->k4_lag0 = !(getenv("UWSPR_K4_LAG0") && atoi(getenv("UWSPR_K4_LAG0")) == 0);
-  c->group_skip_tabled = false; c->cands_from_fdr = false;
-  c->k4_fpack = !(getenv("UWSPR_K4_FPACK") && atoi(getenv("UWSPR_K4_FPACK")) == 0);
-  c->k4f_onegen = !(getenv("UWSPR_K4F_ONEGEN") && atoi(getenv("UWSPR_K4F_ONEGEN")) == 0);
-  c->k5_s5_lanes = getenv("UWSPR_K5_S5_LANES") && atoi(getenv("UWSPR_K5_S5_LANES")) != 0;
-  c->k5_onewave = getenv("UWSPR_K5_ONEWAVE") && atoi(getenv("UWSPR_K5_ONEWAVE")) != 0;
-  c->use_fused = !(getenv("UWSPR_SCHED_FUSED") && atoi(getenv("UWSPR_SCHED_FUSED")) == 0);
-  c->sched_nopad = getenv("UWSPR_SCHED_NOPAD") && atoi(getenv("UWSPR_SCHED_NOPAD")) != 0;
-  // frequency/drift stages through the grid form: parity-tested but measured 9 % SLOWER than the
-  // flat kernel at 5 hypotheses per candidate (4 waves/SIMD, window loads not overlapped): opt-in
-  c->use_stage_grid = getenv("UWSPR_K4_STAGE_GRID") && atoi(getenv("UWSPR_K4_STAGE_GRID")) != 0;
-  c->fast_search = getenv("UWSPR_FAST_SEARCH") && atoi(getenv("UWSPR_FAST_SEARCH")) != 0;
-  c->fast_now = false;
-  if (c->fast_search) c->use_fused = false;   // the fast variant exists for the staged launches only
+  c->cands_from_fdr = false; c->fast_now = false;
   c->cap_slab = 0; c->d_slab = nullptr;
   c->dist_comm = nullptr; c->dist_rank = 0; c->dist_world = 0;
-  c->sched_grid = getenv("UWSPR_SCHED_GRID") ? atoi(getenv("UWSPR_SCHED_GRID")) : 0;
   c->cap_tmpc = 0; c->d_tmpc = nullptr; c->cap_tmpn = 0; c->d_tmpn = nullptr;
   c->h_pin = nullptr; c->pin_busy[0] = c->pin_busy[1] = false;
   c->d_stream_frames = nullptr; c->cap_stream_frames = 0; c->ring_ev = nullptr;
   c->fstride = p->fl; c->np = p->fl < 45000 ? p->fl : 45000;   // sync_and_demodulate_impl.cc:92
   c->cap_ptab = 0; c->d_ptab = nullptr;
-  c->use_ptab = !(getenv("UWSPR_K4_PTAB") && atoi(getenv("UWSPR_K4_PTAB")) == 0);
   c->ntries = UWSPR_NJIG; c->cap_pwin = 0; c->d_pwin = nullptr; c->cap_need = 0; c->d_need = nullptr;
   c->last_slots = 0; c->last_sched_B = 0; c->last_sched_per_frame = 0; c->last_sched_lazy = false; c->last_sched_out = nullptr;
   c->cap_tabs = 0; c->d_tabs = nullptr; c->d_counter = nullptr; c->d_sched_stamps = nullptr; c->cap_sched_stamps = 0;
   *out = c;  // handed back even on failure so uwspr_last_error() can be read
+  {
+    const int orc = options_from_environment(c);
+    if (orc) return orc;
+  }
 
   fdr_consts &f = c->fc;
   memset(&f, 0, sizeof(f));
@@ -266,7 +319,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   }
   // [ifr][u][84] words of 2 x u16 tile byte offsets (coarse_seq_entry); rows with fewer distinct
   // sequences repeat sequence 0
-  const size_t k3_scratch = coarse_plan(f);   // tile form + pitch (k3_coarse.hip)
+  const size_t k3_scratch = coarse_plan(f, c->opt[UWSPR_OPT_K3_PITCH], c->opt[UWSPR_OPT_K3_TILE]);   // tile form + pitch (k3_coarse.hip)
   const int sw = coarse_seq_words();
   std::vector<uint32_t> offw((size_t)f.n_ifr * f.umax * sw, 0u);
   for (int r = 0; r < f.n_ifr; r++)
@@ -752,7 +805,7 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
   }
   if (c->use_fused) {
     // k6_sched: one workgroup per candidate, S0..S5 back to back
-    if (getenv("UWSPR_SCHED_STAMPS") && atoi(getenv("UWSPR_SCHED_STAMPS")) &&
+    if (c->opt[UWSPR_OPT_SCHED_STAMPS] &&
         (rc = ensure(c, &c->d_sched_stamps, &c->cap_sched_stamps, nslots * 64))) return rc;
     if ((rc = ensure(c, &c->d_dout, &c->cap_dout, nslots))) return rc;
     c->cur_dout = user_out ? user_out : c->d_dout;
@@ -780,44 +833,28 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
   if ((rc = ensure(c, &c->d_ptab, &c->cap_ptab, nslots * kPtabPerSlot * kPtabFloat2))) return rc;
   launch_sched_init(c, dcands, dnpk, cand_stride, B, per_frame);
   const bool lazy = njig < UWSPR_NJIG;   // only tries idt < njig of stage 5, packed njig per slot
+  // Staged form, "stage_kernels": 1 (default) = S0 sample-major on packed rows (k4_lag0), S1 / S4 packed frequency stage
+  // (k4_fpack), S3 / S5 LDS ring (k4_ring), S2 flat; 2 = the rows form (k4_rows.hip) for the stage kinds of "rows_mask";
+  // 0 = the flat kernel for every stage (the independent reference form of the equivalence tests).
+  static const int rows_kind[6] = {UWSPR_ROWS_S0, UWSPR_ROWS_S1, -1, UWSPR_ROWS_S3, UWSPR_ROWS_S4, UWSPR_ROWS_S5};
+  const int sk = c->opt[UWSPR_OPT_STAGE_KERNELS];
   for (int s = 0; s < 6; s++) {
     c->fast_now = c->fast_search && s < 5;   // S5 (the soft symbols) is always the reference's arithmetic
     const int H = (int)(nslots * (s == 5 ? njig : hpc[s]));
     const dev_hyp *h = half[s & 1];
-    // lag sweeps (S0, S3, the 17 jiggered shifts) share their tone phasors
-    const bool use_groups = c->use_lag_groups;
-    // frequency / drift stages through the grid form (whole symbol windows on chip)
-    static const float df25[5] = {-2.0f * 0.25f, -1.0f * 0.25f, 0.0f * 0.25f, 1.0f * 0.25f, 2.0f * 0.25f};
-    static const float df05[5] = {-2.0f * 0.05f, -1.0f * 0.05f, 0.0f * 0.05f, 1.0f * 0.05f, 2.0f * 0.05f};
-    static const float zero1[1] = {0.0f}, dd2[2] = {0.5f, -0.5f};
-    bool done = false;
-    if (c->use_stage_grid && (s == 1 || s == 4))
-      done = launch_tonecorr_stage_grid(c, dframes, B, (int)nslots, c->d_cent, c->d_cent_frame, 5,
-                                        s == 1 ? df25 : df05, 1, zero1, c->d_p);
-    else if (c->use_stage_grid && s == 2)
-      done = launch_tonecorr_stage_grid(c, dframes, B, (int)nslots, c->d_cent, c->d_cent_frame, 1, zero1,
-                                        2, dd2, c->d_p);
-    // the rows form: one workgroup per (slot, third of the symbols), sample-major, phasors by scalar loads
-    static const int rows_kind[6] = {UWSPR_ROWS_S0, UWSPR_ROWS_S1, -1, UWSPR_ROWS_S3, UWSPR_ROWS_S4, UWSPR_ROWS_S5};
-    if (done) { /* launched */ }
-    else if (lazy && s == 5) launch_tonecorr(c, dframes, B, h, H, c->d_p);   // few, unrelated lags: the plain kernel
-    else if (c->use_rows && use_groups && c->use_ptab && s != 2) launch_tonecorr_rows(c, dframes, B, rows_kind[s], h, (int)nslots, H, c->d_p);
-    else if (c->use_fstage && (s == 1 || s == 4)) launch_tonecorr_fstage(c, dframes, B, h, (int)nslots, H, c->d_p);
-    else if (use_groups && s == 3 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)nslots, 5, 16, H, c->d_p, 1);
-    else if (use_groups && s == 5 && c->use_lag_ring) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, 8, H, c->d_p, 3);
-    else if (use_groups && s == 0 && c->k4_lag0 && c->use_ptab) {
-      // the slots whose frequency does not depend on the symbol (they have their phasor table) sample-major;
-      // the others -- drifting linear candidates -- through the lag-group kernel, which skips the former.
+    const bool rows = sk == 2 && c->use_ptab && s != 2 && ((c->opt[UWSPR_OPT_ROWS_MASK] >> rows_kind[s]) & 1);
+    if (sk == 0 || s == 2 || (lazy && s == 5)) launch_tonecorr(c, dframes, B, h, H, c->d_p);   // (lazy S5: few, unrelated lags)
+    else if (rows) launch_tonecorr_rows(c, dframes, B, rows_kind[s], h, (int)nslots, H, c->d_p);
+    else if (s == 1 || s == 4) launch_tonecorr_fstage(c, dframes, B, h, (int)nslots, H, c->d_p);
+    else if (s == 3) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)nslots, 5, 16, H, c->d_p, 1);
+    else if (s == 5) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, 8, H, c->d_p, 3);
+    else if (c->use_ptab) {
+      // S0: the slots whose frequency does not depend on the symbol (they have their phasor table) sample-major;
+      // the others -- drifting linear candidates -- through the flat kernel, which leaves the former alone.
       // Candidates from this context's own FDR with maxdrift = 0 have no drift: that launch is not needed.
       launch_tonecorr_lag0(c, dframes, B, c->d_grps, (int)nslots, H, c->d_p);
-      if (!(c->cands_from_fdr && c->p.maxdrift == 0)) {
-        c->group_skip_tabled = true;
-        launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)nslots, 5, H, c->d_p, 1);
-        c->group_skip_tabled = false;
-      }
+      if (!(c->cands_from_fdr && c->p.maxdrift == 0)) launch_tonecorr(c, dframes, B, h, H, c->d_p, c->d_grps, 5);
     }
-    else if (use_groups && (s == 0 || s == 3)) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)nslots, 5, H, c->d_p, 1);
-    else if (use_groups && s == 5) launch_tonecorr_groups(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, H, c->d_p, 3);
     else launch_tonecorr(c, dframes, B, h, H, c->d_p);
     if (s < 5) {
       launch_fold_step(c, s + 1, (int)nslots, njig);   // fold of stage s + transition to stage s+1

@@ -10,6 +10,25 @@
 #include "../../include/uwspr_hip.h"
 #include "stream_ring.h"
 
+// Options of a context, by index (names and defaults: uwspr_api.hip: kOptions; ABI: uwspr_set_option).
+enum {
+  UWSPR_OPT_SCHED = 0,          // 1 fused kernel (default), 0 staged launches
+  UWSPR_OPT_STAGE_KERNELS,      // staged form: 1 packed / ring kernels (default), 0 flat kernel everywhere, 2 rows form
+  UWSPR_OPT_REUSE,              // 1 (default): the hypothesis that repeats the previous stage's winner is not correlated again
+  UWSPR_OPT_PHASOR_TABLES,      // 1 (default)
+  UWSPR_OPT_FAST_SEARCH,        // 0 (default)
+  UWSPR_OPT_ROWS_MASK,          // stage_kernels = 2: bit per stage kind S0,S1,S3,S4,S5 (default 31)
+  UWSPR_OPT_K4_T,               // flat kernel: tones per lane (0 = by size)
+  UWSPR_OPT_K5_LANES,           // fold form: -1 by size (default), 0 wave form, 1 lanes form
+  UWSPR_OPT_K1_ROWS,            // spectrogram rows per wavefront walk (0 = default)
+  UWSPR_OPT_K3_TILE,            // coarse-search tile form (-1 = by size)
+  UWSPR_OPT_K3_PITCH,           // coarse-search tile row pitch (0 = default)
+  UWSPR_OPT_SCHED_STAMPS,       // diagnostics: phase times of the fused kernel
+  UWSPR_OPT_SCHED_GRID,         // fused kernel: workgroups (0 = one per CU)
+  UWSPR_OPT_DIST_FORCE_COMM,    // tests: a one-rank communicator is really created
+  UWSPR_NOPT
+};
+
 namespace uwspr {
 
 // 162 WSPR sync bits (lib/pr3.h:5-13), LSB-first packed; a protocol constant.
@@ -163,7 +182,6 @@ struct uwspr_ctx {
 
   size_t cap_hyps; uwspr::dev_hyp *d_hyps;
   size_t cap_rows; uwspr::dev_row *d_rows;   // [nslots] of the stage being launched (k4_rows.hip)
-  bool use_rows;         // S0/S1/S3/S4/S5 through the rows form (UWSPR_K4_ROWS=0: the round-3 kernels)
   int rows_hs[5];        // hypothesis subsets (wavefronts per tone) of a rows workgroup, per stage kind
   size_t cap_grps; uwspr::dev_grp *d_grps;
   size_t cap_cent; uwspr_candidate *d_cent; int32_t *d_cent_frame;   // per-slot grid centres (S1/S2/S4)
@@ -176,25 +194,21 @@ struct uwspr_ctx {
   // buffers the current call writes (the context's own, or the caller's device memory)
   uwspr_candidate *cur_cands; int32_t *cur_npk; uwspr_demod_out *cur_dout;
   int last_per_frame;
-  bool use_lag_groups, use_stage_grid;
-  bool use_fstage;       // S1/S4 through the frequency-stage form (UWSPR_K4_FSTAGE=0: flat kernel)
-  bool reuse_centre;     // skip the stage-winner hypothesis in S1/S3/S4 (UWSPR_K4_REUSE=0: recompute it)
-  bool use_lag_ring;     // S3/S5 groups through the LDS-ring form (UWSPR_K4_RING=0: plain groups)
-  bool use_k5_lds;       // wave folds through LDS (default); UWSPR_K5_LDS=0: the register / v_readlane form
-  // UWSPR_FAST_SEARCH=1: stages S0..S4 of the schedule with fused multiply-adds and shuffle-tree sums (not
+  // Options (uwspr_set_option; defaults in uwspr_api.hip: kOptions).  The ones the launch sequences branch on:
+  int opt[UWSPR_NOPT];
+  bool opt_set[UWSPR_NOPT];   // set by the caller (environment or uwspr_set_option), not the default
+  bool use_fused;        // "sched" = 1: one workgroup per candidate runs S0..S5 (k6_sched); 0: staged launches
+  bool use_stage_kernels;   // "stage_kernels" >= 1: the staged form's packed / ring / rows kernels; 0: the flat kernel for every stage
+  bool reuse_centre;     // "reuse": skip the stage-winner hypothesis in S1/S3/S4 and try 0 of S5 (0: recompute it)
+  bool use_ptab;         // "phasor_tables": the lag stages read their phasors from per-slot tables (0: every lane runs the recurrence)
+  // "fast_search" = 1: stages S0..S4 of the schedule with fused multiply-adds and shuffle-tree sums (not
   // the reference's arithmetic; S5 and every other entry point stay exact).  fast_now: set around those launches.
   bool fast_search, fast_now;
-  bool k4_lag0;          // S0 through the sample-major packed form for the slots that have a phasor table (UWSPR_K4_LAG0=0: k4_group)
-  bool group_skip_tabled;   // set around the S0 k4_group launch that follows k4_lag0
   bool cands_from_fdr;   // the schedule call's candidates are this context's own FDR output (drift within +-maxdrift)
   uint8_t *next_slab = nullptr; int next_slab_K = 0; bool next_slab_done = false;   // uwspr_pipeline_slabs (one shot)
   int sched_per_frame = 1;   // candidate slots per frame of the schedule being launched
-  bool k4_fpack;         // S1/S4 through the packed form (64 consecutive (slot, symbol) pairs per workgroup); UWSPR_K4_FPACK=0: k4_fstage
-  bool k4f_onegen;       // k4_fstage: wavefront 0 generates all four tones' phasor tables (UWSPR_K4F_ONEGEN=0: each its own)
-  bool k5_s5_lanes;      // UWSPR_K5_S5_LANES=1: the schedule's stage-5 fold through the lanes form (measured slower: 68 long wavefronts)
-  bool k5_onewave;       // UWSPR_K5_ONEWAVE=1: one wavefront per slot folds its hypotheses in turn (5 KB LDS, not 26)
-  // fused schedule (k6_sched: one workgroup per candidate runs S0..S5; UWSPR_SCHED_FUSED=0: staged launches)
-  bool use_fused; bool sched_nopad; int sched_grid;
+  // fused schedule (k6_sched)
+  int sched_grid;
   size_t cap_tabs; float *d_tabs;     // [sched_grid][2][5][4][256](c, s) phasor tables
   int *d_counter;                     // candidate queue head of the running launch
   size_t cap_tmpc; uwspr_candidate *d_tmpc; size_t cap_tmpn; int32_t *d_tmpn;   // uwspr_demod_batch: host records staged
@@ -209,7 +223,6 @@ struct uwspr_ctx {
   int fstride, np;
   int ntries;                         // mode-2 tries per candidate a schedule call produces (uwspr_set_tries)
   size_t cap_ptab; float2 *d_ptab;    // [nslots][kPtabPerSlot][4][256] phasor tables of the lag stages (staged form)
-  bool use_ptab;                      // UWSPR_K4_PTAB=0: every lane runs its own recurrence (same values)
   size_t cap_pwin; float *d_pwin;     // [nslots][162][4] magnitudes of the stage winner (f1, shift1, drift1): try 0 of stage 5, and what uwspr_demod_resume starts from
   size_t cap_need; uint8_t *d_need;   // staging of the resume mask
   int last_slots, last_sched_B, last_sched_per_frame;
@@ -233,11 +246,9 @@ void launch_spectrogram(uwspr_ctx *c, const float *frames, int B);
 void launch_spectrum(uwspr_ctx *c, int B);
 void launch_coarse(uwspr_ctx *c, int B);
 void launch_prep_hyps(uwspr_ctx *c, const uwspr_hyp *abi, dev_hyp *out, int H);
+// flat form; taken != null: hypotheses of groups that have their phasor table are left alone (see k4_tonecorr)
 void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int H,
-                     float4 *p);
-// lag-group form: G groups, each instantiated for NL in {5, 6, 8} lags
-void launch_tonecorr_groups(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
-                            int NL, int64_t nhyps, float4 *p, int groups_per_slot = 1);
+                     float4 *p, const dev_grp *taken = nullptr, int hyps_per_grp = 1);
 void launch_tonecorr_lag0(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int nslots,
                           int64_t nhyps, float4 *p);
 void launch_tonecorr_rows(uwspr_ctx *c, const float *frames, int B, int kind, const dev_hyp *hyps, int nslots,
@@ -250,9 +261,6 @@ void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_gr
 bool launch_tonecorr_grid(uwspr_ctx *c, const float *frames, int B, const uwspr_candidate *centres,
                           int nf, const float *df, int ndrift, const float *ddrift, int nlag,
                           const int *dlag_host, const int *dlag_dev, dev_hyp *hyps, float4 *p);
-bool launch_tonecorr_stage_grid(uwspr_ctx *c, const float *frames, int nframes, int nslots,
-                                const uwspr_candidate *centres, const int32_t *cframe, int nf,
-                                const float *df, int ndrift, const float *ddrift, float4 *p);
 void launch_fold(uwspr_ctx *c, const dev_hyp *hyps, const float4 *p, int H, float *sync,
                  uint8_t *symbols, const float4 *pwin = nullptr, int per_slot = 1);
 void launch_keep_try0(uwspr_ctx *c, int nslots, int njig);

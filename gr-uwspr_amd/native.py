@@ -26,7 +26,7 @@ LIBPATH = os.path.join(LIBDIR, "libuwspr_hip_exp_%s.so" % _EXTRA_TAG if _EXTRA e
 HOSTLIB = os.path.join(LIBDIR, "libuwspr_blocks.so")
 
 SOURCES = ["uwspr_api.hip", "k0_frontend.hip", "k1_spectrogram.hip", "k2_spectrum.hip", "k3_coarse.hip",
-           "k4_tonecorr.hip", "k4_rows.hip", "k5_fold_schedule.hip", "k6_sched.hip", "pipe.hip", "dist.hip", "host_tail.cpp"]
+           "k4_tonecorr.hip", "k4_grid.hip", "k4_rows.hip", "k5_fold_schedule.hip", "k6_sched.hip", "pipe.hip", "dist.hip", "host_tail.cpp"]
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
             "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -153,7 +153,7 @@ assert DECODE_DTYPE.itemsize == 112
 
 class PipeOpts(C.Structure):
     _fields_ = [(k, C.c_int32) for k in ("hop", "batch_frames", "max_per_frame", "lanes", "host_threads", "eager",
-                                         "sched_form", "_reserved")]
+                                         "sched_form", "spare_after_us")]
 
 
 class PipeStats(C.Structure):
@@ -178,7 +178,7 @@ ABI_SYMBOLS = [
     "uwspr_device_alloc", "uwspr_device_free", "uwspr_host_alloc", "uwspr_host_free", "uwspr_fdr_batch",
     "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
     "uwspr_sync_sweep", "uwspr_sync_grid", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
-    "uwspr_pipeline_batch", "uwspr_set_tries", "uwspr_demod_resume", "uwspr_pack_slabs", "uwspr_pipeline_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
+    "uwspr_pipeline_batch", "uwspr_set_tries", "uwspr_set_option", "uwspr_get_option", "uwspr_demod_resume", "uwspr_pack_slabs", "uwspr_pipeline_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
     "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_host_threads", "uwspr_decode_batch", "uwspr_unpack_message",
     "uwspr_c2_read",
     "uwspr_dist_unique_id", "uwspr_dist_init", "uwspr_dist_gather", "uwspr_dist_finalize",
@@ -247,6 +247,8 @@ def lib():
     L.uwspr_demod_batch.argtypes = [vp, vp, ip, ip, vp, vp, ip, ip, vp]
     L.uwspr_pipeline_batch.argtypes = [vp, vp, ip, ip, ip, vp, vp, vp]
     L.uwspr_set_tries.argtypes = [vp, ip]
+    L.uwspr_set_option.argtypes = [vp, C.c_char_p, ip]
+    L.uwspr_get_option.argtypes = [vp, C.c_char_p, vp]
     L.uwspr_demod_resume.argtypes = [vp, vp, ip, ip, vp, ip, vp]
     L.uwspr_pack_slabs.argtypes = [vp, ip, ip, vp, ip]
     L.uwspr_pipeline_slabs.argtypes = [vp, ip, vp]

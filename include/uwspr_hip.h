@@ -295,6 +295,29 @@ int uwspr_demod_batch(uwspr_ctx *ctx, const float *frames, int B, int where,
  * where == UWSPR_HOST (or UWSPR_DEVICE_FRAMES): need is host memory and `out` receives all B*max_per_frame records;
  * UWSPR_DEVICE: need and out are device memory, out being the buffer the first call wrote. */
 int uwspr_set_tries(uwspr_ctx *ctx, int ntries);
+
+/* Options of a context.  The reference's blocks have no run-time switches (their constants are
+ * hard-coded); these choose between forms of THIS implementation that give the same
+ * bytes -- except "fast_search":
+ *   "sched"          1 (default): the whole S0..S5 schedule of a candidate in one workgroup; 0: one launch
+ *                    per stage (what uwspr_pipe_* uses from three lanes up)
+ *   "stage_kernels"  staged form: 1 (default) packed / ring kernels, 2 the rows form, 0 the flat kernel for
+ *                    every stage -- an independent form the equivalence tests compare the others with
+ *   "reuse"          1 (default): the hypothesis that repeats the previous stage's winner
+ *                    (sync_and_demodulate_impl.cc:416-452 evaluate it again and get the same number) is skipped
+ *   "phasor_tables"  1 (default): drift-free stages read the tone phasors of cc:186-199 from per-slot tables
+ *   "fast_search"    0 (default).  1: stages S0..S4 with fused multiply-adds and wavefront shuffle-tree sums --
+ *                    NOT the reference's arithmetic: sync metrics agree to ~1e-6 relative (1e-5 is BASELINE's
+ *                    tolerance), integer results and soft symbols were identical on every frame tried
+ *                    (tests/test_gpu_fast_search.py); stage 5 -- the soft symbols -- and every other entry
+ *                    point stay exact.  Staged form only (it sets "sched" 0).
+ * Further names ("rows_mask", "k4_t", "k5_lanes", "sched_stamps", "sched_grid", "dist_force_comm", and the
+ * creation-time "k1_rows", "k3_tile", "k3_pitch") are diagnostics: DESIGN.md section 9.  The one environment
+ * variable the library reads, UWSPR_OPTIONS="name=value,...", presets options for every context the process
+ * creates.  Unknown names: UWSPR_ERR_ARG. */
+int uwspr_set_option(uwspr_ctx *ctx, const char *name, int value);
+int uwspr_get_option(uwspr_ctx *ctx, const char *name, int *value);
+
 int uwspr_demod_resume(uwspr_ctx *ctx, const float *frames, int B, int where, const uint8_t *need,
                        int max_per_frame, uwspr_demod_out *out);
 
@@ -355,8 +378,8 @@ typedef struct uwspr_pipe_opts {
                              only while every one of the three is busy and a host tail (Fano time-outs) has lasted > 2.5 ms */
   int32_t host_threads;   /* Fano threads (0: uwspr_host_threads() - 2, leaving the producer and the HIP runtime a core each) */
   int32_t eager;          /* 1: all 17 tries in the first pass, no resume (A/B against the lazy flow) */
-  int32_t sched_form;     /* 0: staged launches from 3 lanes up, the fused kernel below (UWSPR_SCHED_FUSED overrides), 1: fused, 2: staged */
-  int32_t _reserved;
+  int32_t sched_form;     /* 0: staged launches from 3 lanes up, the fused kernel below (a "sched" entry of UWSPR_OPTIONS overrides), 1: fused, 2: staged */
+  int32_t spare_after_us; /* a spare lane opens when every base lane is busy and a host tail has lasted this long (0: 2500) */
 } uwspr_pipe_opts;
 /* one refined candidate (j < min(npk, max_per_frame)) of one frame */
 typedef struct uwspr_decode {

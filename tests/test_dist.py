@@ -93,7 +93,7 @@ def test_gather_is_identity_without_a_process_group():
 @pytest.mark.gpu
 def test_c_abi_gather_equals_the_torch_gather_on_one_rank(G, monkeypatch):
     """uwspr_dist_*: the C-ABI gather (RCCL point-to-point transfers to the root) with one rank is the
-    identity, byte-equal to dist.gather_slabs; with UWSPR_DIST_FORCE_COMM=1 a real one-rank RCCL
+    identity, byte-equal to dist.gather_slabs; with option dist_force_comm = 1 a real one-rank RCCL
     communicator is created and destroyed in this process (dlopen + the eight entry points), next to
     whatever collective library PyTorch brought."""
     import torch
@@ -111,7 +111,7 @@ def test_c_abi_gather_equals_the_torch_gather_on_one_rank(G, monkeypatch):
         c.synchronize()
         want = D.gather_slabs(slab)                         # [1, 6, 416]
         for force in ("0", "1"):
-            monkeypatch.setenv("UWSPR_DIST_FORCE_COMM", force)
+            c.set_option("dist_force_comm", int(force))
             uid = G.Context.dist_unique_id()
             assert len(uid) == 128 and any(uid)
             c.dist_init(0, 1, uid)

@@ -77,7 +77,7 @@ def test_spectrogram_rows_per_wavefront_and_wide_band(G, oracle, frames, monkeyp
     batches of these tests): the large-batch walk, an uneven split (22: last group 18 rows) and a
     short one give the same bytes as the oracle; so does the full (unpruned) pass C that a band
     wider than +-64 columns selects (halfbandwidth = 60)."""
-    monkeypatch.setenv("UWSPR_K1_ROWS", rows)
+    monkeypatch.setenv("UWSPR_OPTIONS", "k1_rows=" + rows)   # (shapes the context when it is created)
     for kw in ({}, {"halfbandwidth": 60}):
         c = G.Context(**kw)
         try:
@@ -296,30 +296,27 @@ def test_schedule_matches_oracle(ctx, oracle, frames, vec):
     assert (out[:, 0]["symbols"] == vec["demod_symbols"]).all()
 
 
-def test_schedule_without_lag_groups_is_identical(G, frames, vec, monkeypatch):
-    """The schedule's lag sweeps run through k4_group / k4_ring (shared tone phasors, shared
-    windows) by default and through k4_tonecorr with UWSPR_K4_GROUPS=0: byte-identical output."""
+def test_schedule_forms_are_identical(G, frames, vec):
+    """The refinement schedule exists in four forms -- the fused kernel (k6_sched), the staged launches with the
+    packed / ring kernels (k4_lag0, k4_fpack, k4_ring), the staged launches with the rows form (k4_rows) and the staged
+    launches with the flat kernel (k4_tonecorr) for every stage, the independent form -- each with and without the
+    phasor tables and the stage-winner reuse: byte-identical records."""
     cands = [vec["cands"][b, :int(vec["npk"][b])] for b in range(4)]
     per = max(len(c) for c in cands)
     outs = []
-    for groups, stage_grid, ring, fstage, reuse, fused, k5lds in (
-            ("1", "1", "1", "0", "1", "0", "0"), ("0", "0", "1", "0", "0", "0", "1"), ("1", "0", "0", "1", "1", "0", "0"),
-            ("0", "1", "0", "0", "0", "0", "1"), ("1", "0", "1", "1", "1", "0", "0"), ("0", "0", "0", "1", "0", "0", "0"),
-            ("1", "0", "1", "1", "0", "0", "1"), ("0", "0", "0", "0", "1", "0", "0"), ("1", "0", "1", "1", "1", "0", "1"),
-            ("1", "0", "1", "1", "1", "1", "0"), ("1", "0", "1", "1", "0", "1", "0")):
-        monkeypatch.setenv("UWSPR_K5_LDS", k5lds)            # wave folds: LDS form vs register / v_readlane form
-        monkeypatch.setenv("UWSPR_K5_S5_LANES", reuse)       # stage-5 fold: one lane per try vs one wavefront per try
-        monkeypatch.setenv("UWSPR_K4_PTAB", k5lds)           # lag stages: phasor tables vs per-lane recurrences
-        monkeypatch.setenv("UWSPR_K4_FPACK", groups)         # S1/S4: packed (slot, symbol) pairs vs three parts of 54 symbols
-        monkeypatch.setenv("UWSPR_K4_LAG0", ring)            # S0: sample-major packed form vs the lag-group kernel
-        monkeypatch.setenv("UWSPR_SCHED_FUSED", fused)       # one workgroup per candidate (k6_sched) vs staged launches
-        monkeypatch.setenv("UWSPR_K4_GROUPS", groups)        # lag sweeps: k4_group vs k4_tonecorr
-        monkeypatch.setenv("UWSPR_K4_STAGE_GRID", stage_grid)  # freq/drift stages: k4_grid vs k4_tonecorr
-        monkeypatch.setenv("UWSPR_K4_RING", ring)            # S3/S5 lag groups: k4_ring vs k4_group
-        monkeypatch.setenv("UWSPR_K4_FSTAGE", fstage)        # S1/S4: k4_fstage vs k4_tonecorr
-        monkeypatch.setenv("UWSPR_K4_REUSE", reuse)          # stage-winner hypothesis skipped vs recomputed
-        c = G.Context()
+    for opts in ({"sched": 1},
+                 {"sched": 0, "stage_kernels": 0, "reuse": 0, "phasor_tables": 0},
+                 {"sched": 0, "stage_kernels": 0},
+                 {"sched": 0, "stage_kernels": 1},
+                 {"sched": 0, "stage_kernels": 1, "reuse": 0},
+                 {"sched": 0, "stage_kernels": 1, "phasor_tables": 0},
+                 {"sched": 0, "stage_kernels": 2},
+                 {"sched": 0, "stage_kernels": 2, "reuse": 0},
+                 {"sched": 0, "stage_kernels": 2, "rows_mask": 5},     # rows form for S0 and S3 only
+                 {"sched": 1, "reuse": 0}):
+        c = G.Context(options=opts)
         try:
+            assert all(c.get_option(k) == v for k, v in opts.items())
             outs.append(c.demod_batch(frames, cands, max_per_frame=per))
         finally:
             c.close()
@@ -328,11 +325,19 @@ def test_schedule_without_lag_groups_is_identical(G, frames, vec, monkeypatch):
     assert (outs[0][:, 0]["symbols"] == vec["demod_symbols"]).all()
 
 
-def test_schedule_forms_on_random_candidates(G, oracle, monkeypatch):
+def test_options_are_checked(G, ctx):
+    with pytest.raises(G.UwsprError):
+        ctx.set_option("no_such_option", 1)
+    with pytest.raises(G.UwsprError):
+        ctx.set_option("k3_tile", 1)          # shapes the context at creation: UWSPR_OPTIONS only
+    assert ctx.get_option("sched") in (0, 1)
+
+
+def test_schedule_forms_on_random_candidates(G, oracle):
     """Hand-made candidates that the packed / table kernels must not trip over: frames with 0..5 candidates (dead
     slots between live ones), shifts from before the frame start to the last one whose windows fit, drifting linear
     models (no phasor table: the recurrence kernels take them) next to drift-free and straight-line ones in the same
-    workgroups.  Fused kernel, staged form and staged form with the round-3 kernels switched off: identical bytes;
+    workgroups.  Fused kernel, staged form, staged form with the flat kernel only and the rows form: identical bytes;
     a sample of the records against the oracle."""
     rng = np.random.default_rng(2024)
     frames = np.concatenate([G.synth.make_frames(4, seed=606, snr_db=-17.0),
@@ -357,20 +362,16 @@ def test_schedule_forms_on_random_candidates(G, oracle, monkeypatch):
         cands.append(c)
     cands[0][0]["freq"] = frames.dtype.type(0.0)       # one candidate on the generated signal's grid
     outs = {}
-    for name, env in (("fused", {"UWSPR_SCHED_FUSED": "1"}),
-                      ("staged", {"UWSPR_SCHED_FUSED": "0"}),
-                      ("staged-r2", {"UWSPR_SCHED_FUSED": "0", "UWSPR_K4_LAG0": "0", "UWSPR_K4_FPACK": "0", "UWSPR_K4_PTAB": "0"}),
-                      ("staged-mixed", {"UWSPR_SCHED_FUSED": "0", "UWSPR_K4_LAG0": "1", "UWSPR_K4_FPACK": "0", "UWSPR_K4_RING": "0"})):
-        for k in ("UWSPR_SCHED_FUSED", "UWSPR_K4_LAG0", "UWSPR_K4_FPACK", "UWSPR_K4_PTAB", "UWSPR_K4_RING"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        c = G.Context()
+    for name, opts in (("fused", {"sched": 1}),
+                       ("staged", {"sched": 0}),
+                       ("staged-flat", {"sched": 0, "stage_kernels": 0, "phasor_tables": 0}),
+                       ("staged-rows", {"sched": 0, "stage_kernels": 2})):
+        c = G.Context(options=opts)
         try:
             outs[name] = c.demod_batch(frames, cands, max_per_frame=per)
         finally:
             c.close()
-    for name in ("staged", "staged-r2", "staged-mixed"):
+    for name in ("staged", "staged-flat", "staged-rows"):
         assert outs[name].tobytes() == outs["fused"].tobytes(), name
     for b, j in ((0, 0), (0, 3), (2, 1), (3, 0), (5, 2)):
         d = oracle.demod_candidate(cands[b][j], 1500, frames[b])
@@ -390,16 +391,14 @@ def test_whole_pipeline_on_fresh_and_growing_contexts(G, frames, monkeypatch, fu
     reference configuration (fused form, one context per call), host and device frames, eager and lazy + resume."""
     import torch
     big = np.concatenate([frames, frames[::-1], frames, frames[1:3]])     # 14 frames
-    monkeypatch.setenv("UWSPR_SCHED_FUSED", "1")
     ref = {}
     for name, fr in (("small", frames[:3]), ("big", big)):
-        c = G.Context()
+        c = G.Context(options={"sched": 1})
         try:
             ref[name] = c.pipeline_batch(fr, max_per_frame=2)
         finally:
             c.close()
-    monkeypatch.setenv("UWSPR_SCHED_FUSED", fused)
-    c = G.Context()
+    c = G.Context(options={"sched": int(fused)})
     try:
         for name, fr in (("small", frames[:3]), ("big", big), ("small", frames[:3])):
             cands, out = c.pipeline_batch(fr, max_per_frame=2)
@@ -489,13 +488,8 @@ def test_gather_slabs_kernel_matches_reference_packing(ctx, G, frames):
     ctx.pack_slabs_into(B, D.SLAB_K, host)
     assert (host == got).all()
     # uwspr_pipeline_slabs: the same bytes from the pipeline call itself, both schedule forms, eager and lazy
-    import os
     for fused in ("1", "0"):
-        os.environ["UWSPR_SCHED_FUSED"] = fused
-        try:
-            c2 = G.Context()
-        finally:
-            del os.environ["UWSPR_SCHED_FUSED"]
+        c2 = G.Context(options={"sched": int(fused)})
         try:
             for tries in (17, 1):
                 c2.set_tries(tries)
@@ -811,13 +805,11 @@ def test_fine_search_ignores_samples_from_45000_on(G, oracle):
             cands[b][0]["sync"] = 0.5
         outs = {}
         for fused in ("1", "0"):
-            os.environ["UWSPR_SCHED_FUSED"] = fused
-            c2 = G.Context(fl=fl)
+            c2 = G.Context(fl=fl, options={"sched": int(fused)})
             try:
                 outs[fused] = c2.demod_batch(fr, cands, max_per_frame=1)
             finally:
                 c2.close()
-                os.environ.pop("UWSPR_SCHED_FUSED", None)
         assert outs["1"].tobytes() == outs["0"].tobytes()
         for b in range(2):
             d = oracle.demod_candidate(cands[b][0], 1500, fr[b])
@@ -859,12 +851,11 @@ def test_coarse_search_pruning_is_exact_for_every_threshold(G, oracle, threshold
 
 def test_coarse_search_tile_forms_agree(G, frames, monkeypatch):
     """K3's three tile forms (float4 per centre in LDS -- the default --, plain sqrt rows in LDS,
-    sqrt rows in HBM: UWSPR_K3_TILE = 0 / 1 / 2) and a padded row pitch (UWSPR_K3_PITCH): identical
+    sqrt rows in HBM: option k3_tile = 0 / 1 / 2) and a padded row pitch (k3_pitch): identical
     candidates and identical 16 380 metrics per candidate."""
     res = []
-    for name, v in (("UWSPR_K3_TILE", "0"), ("UWSPR_K3_TILE", "1"), ("UWSPR_K3_TILE", "2"), ("UWSPR_K3_PITCH", "24")):
-        monkeypatch.delenv("UWSPR_K3_TILE", raising=False)
-        monkeypatch.setenv(name, v)
+    for name, v in (("k3_tile", "0"), ("k3_tile", "1"), ("k3_tile", "2"), ("k3_pitch", "24")):
+        monkeypatch.setenv("UWSPR_OPTIONS", name + "=" + v)      # (shape the context when it is created)
         c = G.Context()
         try:
             c.keep_syncgrid(2)
@@ -896,10 +887,9 @@ def test_lazy_tries_and_resume_equal_the_eager_schedule(G, frames, vec, monkeypa
     and the unflagged ones are untouched.  Host and device pointer forms; both schedule forms
     (the staged form runs stage 5 on the k wanted tries only and is resumed by the fused kernel)."""
     import torch
-    monkeypatch.setenv("UWSPR_SCHED_FUSED", fused)
     cands = [vec["cands"][b, :int(vec["npk"][b])] for b in range(4)]
     per = max(len(c) for c in cands)
-    c = G.Context()
+    c = G.Context(options={"sched": int(fused)})
     try:
         eager = c.demod_batch(frames, cands, max_per_frame=per)
         for k in (1, 3):

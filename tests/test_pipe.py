@@ -83,13 +83,12 @@ def test_pipe_on_device_frames_equals_the_sequential_calls(G, eager):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("lanes", [3, 0])
-def test_pipe_on_a_pushed_stream_equals_the_sequential_calls(G, lanes, monkeypatch):
+def test_pipe_on_a_pushed_stream_equals_the_sequential_calls(G, lanes):
     """A 375 S/s stream pushed in ragged pieces (pageable memory through uwspr_pipe_push, page-locked
     through acquire / commit): frames every 3375 samples, batches of 8, a short last batch on flush.
     lanes = 0: the library default (three streams + six spare lanes on the same streams), with the spares opened as
     soon as the three base lanes are busy (the 2.5 ms wait for a slow host tail switched off): same records, same order."""
-    if lanes == 0:
-        monkeypatch.setenv("UWSPR_PIPE_SPARE_AFTER_US", "0")
+    spare_after_us = 1 if lanes == 0 else 0
     hop, fl, nfr, per = 3375, 45000, 27, 1
     base = G.synth.make_frames(4, seed=31415, snr_db=-18.0)
     stream = np.concatenate([base[k][: 10 * hop] for k in range(4)], axis=0)
@@ -101,7 +100,7 @@ def test_pipe_on_a_pushed_stream_equals_the_sequential_calls(G, lanes, monkeypat
         exp = _sequential(G, ctx, want, per)
     finally:
         ctx.close()
-    pipe = G.Pipe(hop=hop, batch_frames=8, max_per_frame=per, lanes=lanes)
+    pipe = G.Pipe(hop=hop, batch_frames=8, max_per_frame=per, lanes=lanes, spare_after_us=spare_after_us)
     try:
         rng = np.random.default_rng(5)
         pos, k = 0, 0

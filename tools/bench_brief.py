@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""One-screen summary of a bench.py JSON line (stdin or a file)."""
+import json
+import sys
+txt = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
+d = json.loads(txt.strip().splitlines()[-1])
+print("value %.0f frames/s  ms/step %.4f  chosen %s" % (d["value"], d["ms_per_step"], d.get("chosen")))
+print("repeats", [round(x) for x in d["repeats"]["frames_per_s"]])
+print("single stream", d.get("single_stream"))
+print("trial ms/step", d["config"].get("trial_ms_per_step"))
+r = d["roofline"]
+print("roofline frac %.4f  kernel_ms_per_step %.4f  achieved %.2f" % (r["frac"], r["kernel_ms_per_step"], r["achieved"]))
+for k in ("end_to_end_decoded", "fast_search"):
+    if k in d:
+        v = d[k]
+        if not isinstance(v, dict):
+            continue
+        print(k, {q: v[q] for q in v if q in ("frames_per_s", "min", "max", "value")})

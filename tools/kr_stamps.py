@@ -49,3 +49,35 @@ t_start = (b[:, 2] - b[:, 2].min()) / 100.0
 t_end = (b[:, 3] - b[:, 2].min()) / 100.0
 print("  wave starts per 4 us bin:", np.bincount((t_start / 4).astype(int)).tolist())
 print("  wave ends   per 4 us bin:", np.bincount((t_end / 4).astype(int)).tolist())
+# ---- per-chunk timeline of the wavefronts of ONE CU
+tl = np.zeros((nw, 16, 4), np.uint64)
+if hasattr(L, "uwspr_debug_kr_timeline") and L.uwspr_debug_kr_timeline(C.c_void_p(tl.ctypes.data), nw) == 0:
+    tl = tl.astype(np.int64)
+    full = buf.astype(np.int64)
+    okw = np.nonzero(full[:, 1] > 0)[0]
+    hw_all = full[okw, 7]
+    hwid_all = hw_all & 0xFFFFFFFF
+    cu_all = (((hw_all >> 32) & 0xF) * 8 + ((hwid_all >> 13) & 7)) * 32 + ((hwid_all >> 12) & 1) * 16 + ((hwid_all >> 8) & 15)
+    simd_all = (hwid_all >> 4) & 3
+    pick = cu_all[0]
+    m = cu_all == pick
+    sel = okw[m]; simd = simd_all[m]
+    t00 = full[sel, 0].min()
+    clk = float(np.median(life / np.maximum(real, 1e-9)))   # MHz
+    print("timeline of one CU (%d wavefronts), us from the first wave's start" % len(sel))
+    print("per workgroup and chunk: arithmetic [first wave out of the turn .. last wave into the next turn], then the turn: "
+          "wait+store / barrier wait / load issue (medians over the workgroup's waves, us)")
+    for g, (wgw, sd) in enumerate(zip(np.array_split(sel, 3), np.array_split(simd, 3))):
+        line = []
+        for c in range(16):
+            if tl[wgw, c, 3].max() == 0:
+                continue
+            nxt = tl[wgw, c + 1, 0] if c + 1 < 16 and tl[wgw, c + 1, 3].max() > 0 else full[wgw, 1]
+            ar = (nxt - tl[wgw, c, 3]) / clk
+            line.append("c%d %.1f-%.1f arith/wave %.2f..%.2f | %.2f/%.2f/%.2f" % (
+                c, (tl[wgw, c, 3].min() - t00) / clk, (nxt.max() - t00) / clk, ar.min(), ar.max(),
+                np.median(tl[wgw, c, 1] - tl[wgw, c, 0]) / clk, np.median(tl[wgw, c, 2] - tl[wgw, c, 1]) / clk,
+                np.median(tl[wgw, c, 3] - tl[wgw, c, 2]) / clk))
+        print("  WG %d (SIMDs %s):" % (g, "".join(str(int(x)) for x in sd)))
+        for x in line:
+            print("     " + x)
