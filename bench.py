@@ -20,9 +20,15 @@ Infinity Cache), so every step ingests frames that are not cache-resident.
 Frames shard with no data-path collective; the one exchange is the final gather.
 
 `--gpus N` run bare (no WORLD_SIZE in the environment) starts the N ranks itself, one
-process per GPU, BEFORE anything touches the GPU in the parent; on a box with fewer
-devices than ranks the ranks share the devices and talk gloo (a rehearsal, flagged
-in the JSON).  Under torch.distributed.run the environment's ranks are used.
+process per GPU, BEFORE anything touches the GPU in the parent.  More ranks than visible
+devices is an error (exit 2) unless --rehearsal is given: the ranks then share the devices
+and talk gloo -- a functional check, flagged in the JSON, not a measurement.  Under
+torch.distributed.run the environment's ranks are used.  With RCCL the slab gather goes
+through the library's own communicator (uwspr_dist_*): unique id broadcast and
+ncclCommInitRank on the main thread, a watchdog that ends the rank with exit code 3 when
+the communicator or its first gather hangs (--comm-timeout), a clean failure falls back to
+torch.distributed's gather; the line carries devices, device_name, rccl_version, the
+gather that was used and whether it equalled torch's gather byte for byte.
 
 The timed region (K steps between barrier + synchronize) is repeated R times
 (default 5); `value` is the MEDIAN repeat, all repeats are listed.
@@ -38,6 +44,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 PMC-measured fabric traffic per launch, VALU issue utilisation from the
                 committed PMC pass.
   cpu_baseline  the CPU restatement (oracle/, kind "port") on a bounded sample.
+  fast_search   `value`'s timed region with option fast_search = 1 (FMA + shuffle-tree stages; never `value`).
+  configs3_n1   BASELINE configs[3] (65 536 frames) on this one GPU: the strong-scaling reference point.
   kernels       HIP-event time per kernel family per step (single stream).
   lazy_s5       the same step with uwspr_set_tries(1): only the first jiggered shift.
   sweep         (N=1) BASELINE configs[2]: 1024 frames x 200 (freq,lag,drift) hypotheses.
@@ -120,9 +128,22 @@ def parse_args():
     ap.add_argument("--gather", choices=("auto", "abi", "torch"), default="auto",
                     help="final slab gather: the library's own RCCL gather (uwspr_dist_*), torch.distributed, or "
                          "auto = the former when its communicator comes up (checked once against the latter)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="allow more ranks than devices (ranks time-slice the GPUs over gloo: functional check, not a "
+                         "measurement); without it such a launch is an error")
+    ap.add_argument("--comm-timeout", type=float, default=120.0,
+                    help="seconds the library's RCCL communicator + its first gather may take before the rank exits 3")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams (each with its own context and scratch) the steps rotate over; 0 = per --sched trial")
     return ap.parse_args()
+
+
+def rccl_version(torch):
+    try:
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:                                    # noqa: BLE001 -- informational only
+        return None
 
 
 def spawn_ranks(args):
@@ -167,6 +188,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     ndev = torch.cuda.device_count()
     rehearsal = ndev < world                  # several ranks on one GPU (gloo)
+    if rehearsal and not args.rehearsal:
+        sys.stderr.write("bench.py: %d ranks but %d visible device(s); pass --rehearsal to time-slice them over gloo "
+                         "(a functional check, not a measurement)\n" % (world, ndev))
+        sys.exit(2)
     local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -252,14 +277,30 @@ def main():
         import threading
         gctx = G.Context(device=local)
         state = {"ok": False, "err": None}
-
-        def _init():
+        # The unique id travels on the MAIN thread and every rank enters the broadcast whatever happened on rank 0
+        # (zeros = rank 0 could not make one): torch's process group sees the same collectives in the same order on
+        # every rank.  ncclCommInitRank and the first gather run on the main thread too, before torch's group is used
+        # for anything else; a watchdog ends THIS rank with exit code 3 if they hang (the launcher then fails the
+        # job: a hung communicator is not something to fall back from silently).
+        uid_t = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
             try:
-                uid_t = torch.zeros(128, dtype=torch.uint8, device=dev)
-                if rank == 0:
-                    uid_t.copy_(torch.frombuffer(bytearray(G.Context.dist_unique_id()), dtype=torch.uint8))
-                dist.broadcast(uid_t, src=0)
-                gctx.dist_init(rank, world, bytes(uid_t.cpu().numpy().tobytes()))
+                uid_t.copy_(torch.frombuffer(bytearray(G.Context.dist_unique_id()), dtype=torch.uint8))
+            except Exception as e:                   # noqa: BLE001
+                state["err"] = "uwspr_dist_unique_id: %r" % (e,)
+        dist.broadcast(uid_t, src=0)
+        uid = bytes(uid_t.cpu().numpy().tobytes())
+        if any(uid):
+            def _hung():
+                sys.stderr.write("bench.py rank %d: RCCL communicator / first gather not up after %.0f s: exit 3\n"
+                                 % (rank, args.comm_timeout))
+                sys.stderr.flush()
+                os._exit(3)
+            wd = threading.Timer(args.comm_timeout, _hung)
+            wd.daemon = True
+            wd.start()
+            try:
+                gctx.dist_init(rank, world, uid)
                 # a first, small gather under the same watchdog: every rank sends 4 KB of its rank number
                 probe = torch.full((4096,), rank, dtype=torch.uint8, device=dev)
                 got = torch.zeros((world, 4096), dtype=torch.uint8, device=dev) if rank == 0 else None
@@ -271,19 +312,19 @@ def main():
                     if not torch.equal(got, want):
                         raise RuntimeError("probe gather returned wrong bytes")
                 state["ok"] = True
-            except Exception as e:                       # noqa: BLE001 -- any failure means: use torch's gather
+            except Exception as e:                       # noqa: BLE001 -- a clean failure means: use torch's gather
                 state["err"] = repr(e)
-
-        th = threading.Thread(target=_init, daemon=True)
-        th.start()
-        th.join(120.0)                   # a communicator (+ its first gather) not up in 2 min is given up
-        okt = torch.tensor([1 if (state["ok"] and not th.is_alive()) else 0], dtype=torch.int32, device=dev)
+            finally:
+                wd.cancel()
+        elif state["err"] is None:
+            state["err"] = "rank 0 could not create a unique id"
+        okt = torch.tensor([1 if state["ok"] else 0], dtype=torch.int32, device=dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         if int(okt.item()) == 1:
             abi_ctx = gctx
             gather_how = "uwspr_dist_gather (RCCL send/recv to the root, C ABI)"
         else:
-            gather_how += "; C-ABI RCCL communicator not used: %s" % (state["err"] or "timed out")
+            gather_how += "; C-ABI RCCL communicator not used: %s" % (state["err"] or "failed on another rank")
 
     def gather_to_root(flat):
         """flat: [n, SLAB_BYTES] uint8 on the device -> [world, n, SLAB_BYTES] on rank 0 (None elsewhere)."""
@@ -360,6 +401,46 @@ def main():
     dt, t_enq = reps[order[len(order) // 2]]
     frames_per_step = args.total_frames if strong else world * B
     rates = [frames_per_step * K / r[0] for r in reps]
+
+    # ---- option "fast_search" (FMA + shuffle-tree stages S0..S4: NOT the reference's arithmetic; never `value`) and
+    # ---- BASELINE configs[3] at N = 1 (65 536 frames through the same lanes: SCALE's strong-scaling reference point)
+    fast_leg = None
+    c3_leg = None
+    if world == 1 and not strong and not args.no_lazy:
+        fl_lanes = make_lanes(3, False, {"fast_search": 1})
+        region(fl_lanes, min(K, 10), gather=False)
+        fr = sorted(region(fl_lanes, K)[0] for _ in range(3))
+        close_lanes(fl_lanes)
+        fast_leg = {"frames_per_s": B * K / fr[1], "ms_per_step": 1e3 * fr[1] / K, "min": B * K / fr[2], "max": B * K / fr[0],
+                    "repeats": 3, "sched": "staged", "streams": 3,
+                    "what": "the timed region of `value` with uwspr_set_option(fast_search, 1): stages S0..S4 with fused "
+                            "multiply-adds and wavefront shuffle-tree sums (sync metrics agree with the exact path to "
+                            "~1e-6, integer results and soft symbols identical: tests/test_gpu_fast_search.py); NOT the "
+                            "reference's arithmetic, so never `value`"}
+        T3 = 65536
+        n3 = T3 // B
+        ring3 = torch.zeros((n3, B, D.SLAB_BYTES), dtype=torch.uint8, device=dev)
+
+        def c3_region():
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(n3):
+                ln = lanes[i % len(lanes)]
+                with torch.cuda.stream(ln["stream"]):
+                    ln["ctx"].pipeline_slabs(D.SLAB_K, ring3[i])
+                    ln["ctx"].pipeline_batch_into(batches[i % nb], ln["cands"], ln["npk"], ln["out"], max_per_frame=1)
+            torch.cuda.synchronize()
+            D.gather_slabs(ring3.view(n3 * B, D.SLAB_BYTES), dst=0)
+            barrier()
+            return time.perf_counter() - t0
+        c3_region()
+        t3s = sorted(c3_region() for _ in range(3))
+        del ring3
+        c3_leg = {"total_frames": n3 * B, "frames_per_s": n3 * B / t3s[1], "ms_total": 1e3 * t3s[1],
+                  "min": n3 * B / t3s[2], "max": n3 * B / t3s[0], "repeats": 3,
+                  "what": "BASELINE configs[3] on ONE GPU: %d frames as %d batches of %d through the lanes of `value`, one "
+                          "gather of all %d slabs at the end (what `--gpus N --total-frames 65536` shards round-robin)"
+                          % (n3 * B, n3, B, n3 * B)}
 
     # ---- per-kernel HIP-event times: single stream, same rotating batches (untimed for `value`) ----
     ctx.prof_enable(True)
@@ -629,6 +710,8 @@ def main():
                        "trial_ms_per_step": {("%s x%d streams" % ("fused" if f else "staged", s)): 1e3 * v / K
                                              for (f, s), v in trials.items()},
                        "rehearsal_ranks_share_devices": bool(rehearsal), "backend": backend, "devices": min(ndev, world),
+                       "devices_visible": ndev, "device_name": torch.cuda.get_device_name(local),
+                       "rccl_version": rccl_version(torch),
                        "gather": gather_how, "gather_equals_torch_gather": gather_checked},
             "roofline": {"kernel": "k6_sched" if fused else "k4_* (6 launches)", "bound": "valu_fp32_nofma",
                          "achieved": achieved_tops, "peak": FP32_NOFMA_PEAK_TOPS, "unit": "Top/s",
@@ -649,6 +732,8 @@ def main():
                                      "from HBM (SURVEY 8(d)); not an HBM utilisation: the measured fabric traffic is "
                                      "`traffic`"}},
             "kernels": kern,
+            "fast_search": fast_leg,
+            "configs3_n1": c3_leg,
             "lazy_s5": lazy,
             "host_pointer_frames_per_s_pcie_inclusive": host_rate,
             "host_pinned_pointer_frames_per_s_pcie_inclusive": host_pinned_rate,

@@ -390,7 +390,7 @@ __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
                              const int32_t *__restrict__ npk, int cand_stride, int B,
                              int per_frame, float cf, cand_state *__restrict__ state,
                              dev_hyp *__restrict__ hyps, dev_grp *__restrict__ grps, float2 *__restrict__ ptab,
-                             dev_row *__restrict__ rows) {
+                             dev_row *__restrict__ rows, int all_a) {
   UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   // one wavefront per slot: every lane derives the same state (lane 0 writes it), lanes 0..19 build table set A
   const int slot = blockIdx.x;
@@ -422,7 +422,9 @@ __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
   // two differ in the sign of a zero.
   st.tabA_f = f0; st.tabB_f = 0.0f; st.tabB_ok = 0;
   st.tabA_ok = (ptab != nullptr && on && (st.m_type != UWSPR_LINEAR || st.drift1 == 0.0f)) ? 1 : 0;
-  if (st.tabA_ok) ptab_build(ptab + (size_t)slot * kPtabPerSlot * kPtabFloat2, 5, 0, f0, 0.25f, st.m_type, st.drift1, st.slmc);
+  // (all five only when a kernel reads them: the rows form's S1; S0 reads the middle one)
+  if (st.tabA_ok && all_a) ptab_build(ptab + (size_t)slot * kPtabPerSlot * kPtabFloat2, 5, 0, f0, 0.25f, st.m_type, st.drift1, st.slmc);
+  else if (st.tabA_ok) ptab_build(ptab + ((size_t)slot * kPtabPerSlot + 2) * kPtabFloat2, 1, 2, f0, 0.25f, st.m_type, st.drift1, st.slmc);
   if (threadIdx.x != 0) return;
   state[slot] = st;
   dev_hyp *h = hyps + (size_t)slot * 5;
@@ -761,7 +763,7 @@ void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t
   prof_scope ps(c, UWSPR_K_SCHED, nslots);
   hipLaunchKernelGGL(k_sched_init, dim3(nslots), dim3(64), 0, c->stream, cands,
                      npk, cand_stride, B, per_frame, (float)c->p.cf, c->d_state, c->d_hyps, c->d_grps,
-                     c->use_ptab ? c->d_ptab : nullptr, c->d_rows);
+                     c->use_ptab ? c->d_ptab : nullptr, c->d_rows, c->opt[UWSPR_OPT_STAGE_KERNELS] == 2 ? 1 : 0);
 }
 
 // hyps of consecutive stages ping-pong between the two halves of d_hyps;

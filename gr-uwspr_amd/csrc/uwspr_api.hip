@@ -110,7 +110,7 @@ static void refresh_options(uwspr_ctx *c) {
   c->reuse_centre = c->opt[UWSPR_OPT_REUSE] != 0;
   c->use_ptab = c->opt[UWSPR_OPT_PHASOR_TABLES] != 0;
   c->fast_search = c->opt[UWSPR_OPT_FAST_SEARCH] != 0;
-  if (c->fast_search) c->use_fused = false;   // the fast variant exists for the staged launches only
+  if (c->fast_search) { c->use_fused = false; c->opt[UWSPR_OPT_SCHED] = 0; }   // the fast variant exists for the staged launches only
   c->sched_grid = c->opt[UWSPR_OPT_SCHED_GRID];
 }
 

@@ -1,0 +1,75 @@
+"""Option "fast_search" (the north-star's FMA + wavefront-shuffle form of the search stages).
+
+Stages S0..S4 of the refinement schedule (sync_and_demodulate_impl.cc:409-452) with fused multiply-adds and
+shuffle-tree sums are NOT the reference's arithmetic: a sync metric carries one rounding per product-sum instead of
+two and a different summation order.  What the option promises -- and what this file pins over 2 100 seeded frames
+from -18 dB to -31 dB and noise only, every refined candidate:
+
+  * every integer result (shift1, worth_a_try, the 17 jiggered shifts), f1 and drift1 (picked from discrete grids)
+    and every soft-symbol byte (stage 5 stays on the exact kernels) equals the exact path's;
+  * sync1 within BASELINE's tolerance, 1e-5 relative -- relative to max(|sync1|, 0.1): 0.1 is minsync1, the gate
+    the value is compared with (cc:329, 443); a metric of 0.003 on a dead candidate has no relative precision to keep;
+  * jig_sync / jig_rms (stage 5) bit-equal;
+  * the coarse search (FDR) is untouched.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SNRS = (-18.0, -22.0, -25.0, -27.0, -29.0, -31.0, None)
+CHUNK, PER = 300, 2
+
+
+def test_fast_search_agrees_with_the_exact_schedule(G):
+    cx = G.Context(options={"sched": 0})
+    cf = G.Context(options={"fast_search": 1})
+    assert cf.get_option("sched") == 0                      # the fast variant exists for the staged launches only
+    ncand = nworth = 0
+    worst = 0.0
+    try:
+        for k, snr in enumerate(SNRS):
+            if snr is None:
+                fr = (0.5 * np.random.default_rng(k).standard_normal((CHUNK, 45000, 2))).astype(np.float32)
+            else:
+                fr = G.synth.make_frames(CHUNK, seed=0xFA57 + 1000 * k, snr_db=snr, maxdrift=0.0)
+            ce, oe = cx.pipeline_batch(fr, max_per_frame=PER)
+            cq, of = cf.pipeline_batch(fr, max_per_frame=PER)
+            for b in range(CHUNK):
+                assert ce[b].tobytes() == cq[b].tobytes()          # the coarse search is untouched
+                for j in range(min(PER, len(ce[b]))):
+                    a, f = oe[b, j], of[b, j]
+                    ncand += 1
+                    nworth += int(a["worth_a_try"])
+                    where = (snr, b, j)
+                    assert int(a["shift1"]) == int(f["shift1"]) and int(a["worth_a_try"]) == int(f["worth_a_try"]), where
+                    assert np.float32(a["f1"]).tobytes() == np.float32(f["f1"]).tobytes(), where
+                    assert np.float32(a["drift1"]).tobytes() == np.float32(f["drift1"]).tobytes(), where
+                    err = abs(float(f["sync1"]) - float(a["sync1"])) / max(abs(float(a["sync1"])), 0.1)
+                    worst = max(worst, err)
+                    assert err <= 1e-5, (where, float(a["sync1"]), float(f["sync1"]))
+                    assert (a["jig_shift"] == f["jig_shift"]).all(), where
+                    assert a["symbols"].tobytes() == f["symbols"].tobytes(), where
+                    assert a["jig_sync"].tobytes() == f["jig_sync"].tobytes(), where
+                    assert a["jig_rms"].tobytes() == f["jig_rms"].tobytes(), where
+    finally:
+        cx.close()
+        cf.close()
+    assert ncand >= 1500 and nworth >= 1000, (ncand, nworth)     # (2 100 frames; noise-only ones often yield no candidate)
+    print("fast_search: %d candidates (%d worth a try), worst sync1 error %.2e of the gate scale" % (ncand, nworth, worst))
+
+
+def test_fast_search_is_switched_per_context(G):
+    """The option is a property of the context (uwspr_set_option), not of the process: switching it off again gives
+    the exact bytes back."""
+    fr = G.synth.make_frames(6, seed=777, snr_db=-24.0)
+    c = G.Context(options={"sched": 0})
+    try:
+        exact = c.pipeline_batch(fr, max_per_frame=1)[1]
+        c.set_option("fast_search", 1)
+        c.pipeline_batch(fr, max_per_frame=1)
+        c.set_option("fast_search", 0)
+        again = c.pipeline_batch(fr, max_per_frame=1)[1]
+        assert exact.tobytes() == again.tobytes()
+    finally:
+        c.close()
