@@ -587,6 +587,10 @@ class Pipe:
         n = self._chk(self.L.uwspr_pipe_collect(self.h, C.c_void_p(out.ctypes.data), cap, 1 if wait else 0))
         return out[:n].copy()
 
+    def inject_failure(self, batch, where):
+        """test hook: batch number `batch` fails at its launch (where = 0) or in its host tail (where = 1)"""
+        self._chk(self.L.uwspr_pipe_inject_failure(self.h, int(batch), int(where)))
+
     def stats(self):
         st = N.PipeStats()
         self._chk(self.L.uwspr_pipe_get_stats(self.h, C.byref(st)))

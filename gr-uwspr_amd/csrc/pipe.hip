@@ -74,7 +74,11 @@ struct uwspr_pipe {
   uwspr_pipe_opts o;
   int device = 0, fl = 0, maxfreqs = 0, per = 1;
   char err[512];
-  int failed = 0;   // sticky status of the first failure (coordinator or producer)
+  // Sticky status of the first RUNTIME failure (HIP, a lane's context), written by coordinators and the producer, read
+  // by both without the lock.  Argument errors are not sticky: the call that made them returns UWSPR_ERR_ARG (with
+  // its message), nothing in flight is harmed and the pipe goes on.
+  std::atomic<int> failed{0};
+  int64_t inject_seq = -1; int inject_where = 0;   // uwspr_pipe_inject_failure (tests)
 
   std::vector<pipe_lane> lanes;
   double spare_after = 2.5e-3;   // seconds of host tail after which a spare lane may open (take_lane)
@@ -103,15 +107,29 @@ struct uwspr_pipe {
 static int pfail(uwspr_pipe *q, int status, const char *fmt, ...) {
   if (q) {
     std::lock_guard<std::mutex> lk(q->m);
-    if (!q->failed) {
+    if (!q->failed.load()) {
       va_list ap;
       va_start(ap, fmt);
       vsnprintf(q->err, sizeof(q->err), fmt, ap);
       va_end(ap);
-      q->failed = status;
+      q->failed.store(status);
     }
   }
+  if (q) q->cv_done.notify_all();   // (a collector waiting for records learns of the failure)
   return status;
+}
+// an argument error of the calling thread: message, status, nothing sticky
+static int parg(uwspr_pipe *q, const char *fmt, ...) {
+  if (q) {
+    std::lock_guard<std::mutex> lk(q->m);
+    if (!q->failed.load()) {
+      va_list ap;
+      va_start(ap, fmt);
+      vsnprintf(q->err, sizeof(q->err), fmt, ap);
+      va_end(ap);
+    }
+  }
+  return UWSPR_ERR_ARG;
 }
 
 #define PHIP(q, call)                                                                               \
@@ -127,6 +145,7 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
   L.recs.clear();   // (a failure below emits nothing for this batch)
   double t0 = now_s();
   PHIP(q, hipEventSynchronize(L.ev_done));
+  if (q->inject_where == 1 && L.seq == q->inject_seq) return pfail(q, UWSPR_ERR_HIP, "injected failure in the host tail of batch %lld", (long long)L.seq);
   double t1 = now_s();
   {
     std::lock_guard<std::mutex> lk(q->m);
@@ -239,7 +258,7 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
 
 // A coordinator takes the oldest launched batch nobody has taken yet, finishes it and emits its records when the
 // batches before it have been emitted.  ncoords threads run this loop (default: one per lane, so that the host
-// tails of consecutive batches overlap; UWSPR_PIPE_COORDS=1: strictly one batch after the other).
+// tails of consecutive batches overlap).
 static void coordinator(uwspr_pipe *q) {
   (void)hipSetDevice(q->device);
   for (;;) {
@@ -277,7 +296,7 @@ static void coordinator(uwspr_pipe *q) {
 // host tail is the bottleneck -- Fano time-outs, 4 ms of a core each: a spare is opened only while every base lane is busy
 // and one of them has been in its host tail (first GPU pass complete) for longer than kSpareAfter (2.5 ms).
 constexpr double kSpareAfter = 2.5e-3;   // seconds (a Fano time-out is ~4 ms; the host tail of a batch that decodes at once ~0.3 ms)
-// (UWSPR_PIPE_SPARE_AFTER_US, read when a pipe is opened: tests open the spares at once with 0)
+// (uwspr_pipe_opts::spare_after_us: tests open the spares at once with 1)
 static pipe_lane *take_lane(uwspr_pipe *q) {
   std::unique_lock<std::mutex> lk(q->m);
   const int n = (int)q->lanes.size(), base = n < kPipeStreams ? n : kPipeStreams;
@@ -308,6 +327,8 @@ static int launch(uwspr_pipe *q, pipe_lane &L, const float *frames, int B, int s
   const int per = q->per;
   L.B = B; L.stride = stride; L.frames = frames; L.pos0 = pos0; L.frame0 = q->next_frame;
   q->next_frame += B;
+  if (q->inject_where == 0 && q->next_seq == q->inject_seq)
+    return pfail(q, UWSPR_ERR_HIP, "injected failure at the launch of batch %lld", (long long)q->next_seq);
   int rc = uwspr_set_frame_stride(L.ctx, stride);
   if (!rc) rc = uwspr_set_tries(L.ctx, q->o.eager ? UWSPR_NJIG : 1);
   if (!rc) rc = uwspr_pipeline_batch(L.ctx, frames, B, UWSPR_DEVICE, per, L.d_cands, L.d_npk, L.d_out);
@@ -433,15 +454,9 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
     PHIP(q, hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming | hipEventBlockingSync));
     L.dec.resize((size_t)Bm * per); L.idt.resize((size_t)Bm * per); L.msg.resize((size_t)Bm * per * 7);
   }
-  // pushed streams: the device ring (a few batches of slack beyond what can be in flight) and the
-  // page-locked staging buffers the producer fills
-  if (!q->ring.open(p->fl, q->o.hop, Bm, q->o.lanes + 3))
-    return pfail(q, UWSPR_ERR_NOMEM, "stream ring: %s", hipGetErrorString(q->ring.err));
+  // pushed streams: the device ring and the page-locked staging buffers are made by the first acquire (open_ingest):
+  // a pipe that only takes device frames (uwspr_pipe_submit_device) never pays their 2.2 GB + 0.37 GB (defaults)
   q->stage_samples = (size_t)Bm * q->o.hop;
-  for (int k = 0; k < uwspr_pipe::NSTAGE; k++) {
-    PHIP(q, hipHostMalloc((void **)&q->h_stage[k], q->stage_samples * 2 * sizeof(float), hipHostMallocDefault));
-    PHIP(q, hipEventCreateWithFlags(&q->stage_ev[k], hipEventDisableTiming));
-  }
   if (q->o.host_threads <= 0) q->o.host_threads = host_cpu_share() > 3 ? host_cpu_share() - 2 : 1;
   q->pool = &host_pool::shared();   // the process-wide pool; this pipe's jobs use host_threads of it
   const int ncoords = (int)q->lanes.size();
@@ -449,12 +464,32 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
   return UWSPR_OK;
 }
 
+// the device ring (a few batches of slack beyond what can be in flight) and the page-locked staging buffers
+static int open_ingest(uwspr_pipe *q) {
+  if (q->ring.is_open()) return UWSPR_OK;
+  if (!q->ring.open(q->fl, q->o.hop, q->o.batch_frames, q->o.lanes + 3))
+    return pfail(q, UWSPR_ERR_NOMEM, "stream ring: %s", hipGetErrorString(q->ring.err));
+  for (int k = 0; k < uwspr_pipe::NSTAGE; k++) {
+    PHIP(q, hipHostMalloc((void **)&q->h_stage[k], q->stage_samples * 2 * sizeof(float), hipHostMallocDefault));
+    PHIP(q, hipEventCreateWithFlags(&q->stage_ev[k], hipEventDisableTiming));
+  }
+  return UWSPR_OK;
+}
+
+extern "C" int uwspr_pipe_inject_failure(uwspr_pipe *q, long long batch, int where) {
+  if (!q || where < 0 || where > 1) return UWSPR_ERR_ARG;
+  std::lock_guard<std::mutex> lk(q->m);
+  q->inject_seq = batch; q->inject_where = where;
+  return UWSPR_OK;
+}
+
 extern "C" int uwspr_pipe_acquire(uwspr_pipe *q, int nsamples, float **iq) {
   if (!q || !iq) return UWSPR_ERR_ARG;
-  if (q->failed) return q->failed;
+  if (const int f = q->failed.load()) return f;
   if (nsamples <= 0 || (size_t)nsamples > q->stage_samples)
-    return pfail(q, UWSPR_ERR_ARG, "uwspr_pipe_acquire(%d): at most %zu samples per piece", nsamples, q->stage_samples);
+    return parg(q, "uwspr_pipe_acquire(%d): at most %zu samples per piece", nsamples, q->stage_samples);
   (void)hipSetDevice(q->device);
+  if (const int rc = open_ingest(q)) return rc;
   const int s = q->stage_next;
   if (q->stage_busy[s]) { PHIP(q, hipEventSynchronize(q->stage_ev[s])); q->stage_busy[s] = false; }
   q->stage_cur = s;
@@ -464,9 +499,9 @@ extern "C" int uwspr_pipe_acquire(uwspr_pipe *q, int nsamples, float **iq) {
 
 extern "C" int uwspr_pipe_commit(uwspr_pipe *q, int nsamples) {
   if (!q) return UWSPR_ERR_ARG;
-  if (q->failed) return q->failed;
+  if (const int f = q->failed.load()) return f;
   if (q->stage_cur < 0 || nsamples < 0 || (size_t)nsamples > q->stage_samples)
-    return pfail(q, UWSPR_ERR_ARG, "uwspr_pipe_commit(%d) without a matching uwspr_pipe_acquire", nsamples);
+    return parg(q, "uwspr_pipe_commit(%d) without a matching uwspr_pipe_acquire", nsamples);
   (void)hipSetDevice(q->device);
   const int s = q->stage_cur;
   q->stage_cur = -1;
@@ -506,9 +541,9 @@ extern "C" int uwspr_pipe_push(uwspr_pipe *q, const float *iq, int nsamples) {
 
 extern "C" int uwspr_pipe_submit_device(uwspr_pipe *q, const float *dev_frames, int B, int stride) {
   if (!q || !dev_frames) return UWSPR_ERR_ARG;
-  if (q->failed) return q->failed;
+  if (const int f = q->failed.load()) return f;
   if (B <= 0 || B > q->o.batch_frames || stride < 0)
-    return pfail(q, UWSPR_ERR_ARG, "uwspr_pipe_submit_device: B=%d (1..%d) stride=%d", B, q->o.batch_frames, stride);
+    return parg(q, "uwspr_pipe_submit_device: B=%d (1..%d) stride=%d", B, q->o.batch_frames, stride);
   (void)hipSetDevice(q->device);
   pipe_lane *L = take_lane(q);
   const int rc = launch(q, *L, dev_frames, B, stride > 0 ? stride : q->fl, -1, -1);
@@ -519,7 +554,7 @@ extern "C" int uwspr_pipe_submit_device(uwspr_pipe *q, const float *dev_frames, 
 extern "C" int uwspr_pipe_flush(uwspr_pipe *q) {
   if (!q) return UWSPR_ERR_ARG;
   (void)hipSetDevice(q->device);
-  while (!q->failed && q->ring.is_open() && q->ring.ready() > 0) {
+  while (!q->failed.load() && q->ring.is_open() && q->ring.ready() > 0) {
     const int k = q->ring.ready() < q->o.batch_frames ? q->ring.ready() : q->o.batch_frames;
     const int rc = launch_from_ring(q, k);
     if (rc) return rc;
@@ -529,7 +564,7 @@ extern "C" int uwspr_pipe_flush(uwspr_pipe *q) {
     for (auto &L : q->lanes) if (L.busy) return false;
     return true;
   });
-  return q->failed;
+  return q->failed.load();
 }
 
 extern "C" int uwspr_pipe_collect(uwspr_pipe *q, uwspr_decode *out, int cap, int wait) {
@@ -537,11 +572,11 @@ extern "C" int uwspr_pipe_collect(uwspr_pipe *q, uwspr_decode *out, int cap, int
   std::unique_lock<std::mutex> lk(q->m);
   if (wait)
     q->cv_done.wait(lk, [&]() {
-      if (!q->done.empty() || q->failed) return true;
+      if (!q->done.empty() || q->failed.load()) return true;
       for (auto &L : q->lanes) if (L.busy) return false;
       return true;
     });
-  if (q->failed && q->done.empty()) return q->failed;
+  if (q->failed.load() && q->done.empty()) return q->failed.load();
   int n = 0;
   while (n < cap && !q->done.empty()) { out[n++] = q->done.front(); q->done.pop_front(); }
   return n;

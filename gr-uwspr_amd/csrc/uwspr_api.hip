@@ -1033,6 +1033,13 @@ extern "C" int uwspr_stream_take(uwspr_ctx *c, int nframes, float *dev_dst, cons
 extern "C" int uwspr_stream_reset(uwspr_ctx *c, long long pos) {
   int rc = ready(c);
   if (rc) return rc;
+  // The kernels of the LAST view may still be enqueued (a view records the readers of the views BEFORE it): put the
+  // buffers' next writer -- an append after the reset switches buffers, a second reset switches back -- behind
+  // everything the stream holds now, as a take does.
+  if (c->ring.is_open() && c->ring_ev) {
+    HIPCHK(c, hipEventRecord(c->ring_ev, c->stream));
+    c->ring.reader_done(0, c->ring_ev); c->ring.reader_done(1, c->ring_ev);
+  }
   c->ring.reset(pos);
   return UWSPR_OK;
 }

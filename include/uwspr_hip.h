@@ -417,6 +417,12 @@ int uwspr_pipe_flush(uwspr_pipe *pipe);
  * in flight.  returns the count (>= 0) or a negative status. */
 int uwspr_pipe_collect(uwspr_pipe *pipe, uwspr_decode *out, int cap, int wait);
 int uwspr_pipe_get_stats(uwspr_pipe *pipe, uwspr_pipe_stats *st);
+/* Error behaviour.  An argument error (too many samples, a bad B or stride) fails THAT call with UWSPR_ERR_ARG and
+ * its message; the pipe goes on.  A runtime failure (HIP, a lane's context) is sticky: the batch it hit emits
+ * nothing, records of the batches before it stay collectable, every later call -- and uwspr_pipe_collect once
+ * those records are gone -- returns the status; uwspr_pipe_close always returns.
+ * Test hook: the batch with running number `batch` fails at its launch (where = 0) or in its host tail (where = 1). */
+int uwspr_pipe_inject_failure(uwspr_pipe *pipe, long long batch, int where);
 
 /* ---- measurement -------------------------------------------------------- */
 enum { UWSPR_K_SPECTROGRAM = 0, UWSPR_K_SPECTRUM = 1, UWSPR_K_COARSE = 2,

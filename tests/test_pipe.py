@@ -126,12 +126,109 @@ def test_pipe_on_a_pushed_stream_equals_the_sequential_calls(G, lanes):
 
 
 @pytest.mark.gpu
-def test_pipe_argument_errors(G):
+def test_pipe_argument_errors_are_not_sticky(G):
+    """An argument error fails the call that made it (status + message) and nothing else: the pipe goes on and
+    gives the records of the sequential calls."""
+    import torch
     with pytest.raises(G.UwsprError):
         G.Pipe(hop=50000)
+    fr = G.synth.make_frames(4, seed=99, snr_db=-18.0)
+    ctx = G.Context()
+    try:
+        exp = _sequential(G, ctx, fr, 1)
+    finally:
+        ctx.close()
     pipe = G.Pipe(batch_frames=4)
     try:
+        with pytest.raises(G.UwsprError) as e:
+            pipe.acquire(4 * 45000 + 1)
+        assert e.value.status == -6 and "at most" in str(e.value)      # UWSPR_ERR_ARG
+        dev = torch.from_numpy(fr).cuda()
+        with pytest.raises(G.UwsprError) as e:
+            pipe.submit_device(dev, stride=-5)
+        assert e.value.status == -6
         with pytest.raises(G.UwsprError):
-            pipe.acquire(4 * 3375 + 1)
+            pipe.commit(10)                                   # no matching acquire
+        pipe.submit_device(dev)                               # ... and the pipe still works
+        pipe.flush()
+        assert _as_dict(pipe.collect()) == exp
     finally:
         pipe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", [0, 1])
+def test_pipe_runtime_failure_mid_stream(G, where):
+    """A runtime failure on batch 2 of 5 (injected at its launch / in its host tail): batches 0 and 1 emit their records
+    as the sequential calls give them, batch 2 emits nothing, the status is sticky -- submit, flush and (once the good
+    records are gone) collect return it -- and close returns."""
+    import torch
+    fr = G.synth.make_frames(20, seed=4711, snr_db=-18.0)
+    ctx = G.Context()
+    try:
+        exp = _sequential(G, ctx, fr[:8], 1)
+    finally:
+        ctx.close()
+    dev = torch.from_numpy(fr).cuda()
+    pipe = G.Pipe(batch_frames=4, lanes=3)
+    try:
+        pipe.inject_failure(2, where)
+        failed_at = None
+        for k in range(5):
+            try:
+                pipe.submit_device(dev[4 * k: 4 * k + 4])
+            except G.UwsprError as e:
+                failed_at = k
+                assert e.status == -4 and "injected" in str(e)
+                break
+        assert failed_at is None or failed_at >= 2                # (where = 1: the producer learns of it a call or two later, or in flush)
+        assert where == 1 or failed_at == 2
+        with pytest.raises(G.UwsprError) as e:
+            pipe.flush()
+        assert e.value.status == -4
+        recs = pipe.collect()                                     # what was emitted before the failure stays collectable
+        got = _as_dict(recs)
+        assert set(int(f) for f in recs["frame"]) >= set(range(8)) and not (set(int(f) for f in recs["frame"]) & {8, 9, 10, 11})
+        assert {k: v for k, v in got.items() if k[0] < 8} == exp
+        with pytest.raises(G.UwsprError):
+            pipe.collect(wait=True)                               # nothing left: the status
+        with pytest.raises(G.UwsprError):
+            pipe.submit_device(dev[:4])
+    finally:
+        pipe.close()                                              # returns
+
+
+@pytest.mark.gpu
+def test_pipe_stream_longer_than_the_device_ring(G):
+    """A pushed stream several times the ring's capacity (batches of 2 frames, 3 lanes: (3 + 3) * 2 * 3375 + 45000 =
+    85 500 samples per buffer; 320 frames = 1.12 M samples): the tail moves between the two buffers a dozen times
+    while earlier views are still being read, marginal transmissions are resumed from frames the ring has moved
+    past -- byte-equal to the sequential calls on the same windows."""
+    hop, fl, nfr, per = 3375, 45000, 320, 1
+    base = G.synth.make_frames(28, seed=2718, snr_db=-26.5)
+    stream = np.concatenate([base[k][: 12 * hop] for k in range(28)], axis=0)
+    stream = np.ascontiguousarray(stream[: fl + (nfr - 1) * hop])
+    assert len(stream) == fl + (nfr - 1) * hop
+    want = np.stack([stream[k * hop: k * hop + fl] for k in range(nfr)])
+    ctx = G.Context()
+    try:
+        exp = _sequential(G, ctx, want, per)
+    finally:
+        ctx.close()
+    pipe = G.Pipe(hop=hop, batch_frames=2, max_per_frame=per, lanes=3)
+    try:
+        rng = np.random.default_rng(17)
+        pos = 0
+        while pos < len(stream):
+            n = min(int(rng.integers(500, 2 * hop)), len(stream) - pos)
+            pipe.push(stream[pos: pos + n])
+            pos += n
+        pipe.flush()
+        recs = pipe.collect()
+        st = pipe.stats()
+    finally:
+        pipe.close()
+    assert st["frames"] == nfr and st["batches"] == nfr // 2
+    assert (recs["stream_pos"] == recs["frame"] * hop).all()
+    assert _as_dict(recs) == exp
+    assert st["resumed"] >= 1 and st["decoded"] >= 10
