@@ -64,7 +64,7 @@ constexpr int K3_THREADS = K3_THREADS_N;
 // float4, no conflict inside a ds_read_b128 lane group), but a group that straddles two cells reads
 // rows one apart, i.e. float4 indices tp + (difference of offsets) apart: with tp = nc = 13 every
 // pair three columns apart collides (27 % of the kernel's LDS cycles); tp = 8 (mod 16) leaves only the
-// pairs eight columns apart (UWSPR_K3_PITCH=24; see coarse_tile_pitch() for why it is not the default).
+// pairs eight columns apart (option "k3_pitch"=24; see coarse_tile_pitch() for why it is not the default).
 //
 // Three tile forms (fdr_consts::k3_mode, chosen at context creation by what fits the 160 KB of LDS):
 //   K3_TILE_F4     float4 {sqrt ps[c-3], [c-1], [c+1], [c+3]} per (row, centre c) in LDS: one

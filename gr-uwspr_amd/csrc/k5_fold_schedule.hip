@@ -537,7 +537,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     }
     // try 0 is (f1, shift1, drift1): the hypothesis that just won stage 4 (cc:457-463 with idt = 0) -- known
     // when one did: its magnitudes are the kept ones, K4 leaves it out, the fold reads the kept row
-    // (UWSPR_FAST_SEARCH: the kept magnitudes come from the fused-multiply-add stages; stage 5 is always the
+    // (option "fast_search": the kept magnitudes come from the fused-multiply-add stages; stage 5 is always the
     // reference's arithmetic, so try 0 is correlated again there)
     const bool known0 = reuse && !fast && st.worth && st.sync1 > -1e30f;
     st.cknown = known0 ? 1 : 0;
@@ -579,7 +579,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
 
 // Fold of a candidate's NIN hypotheses (one wavefront each) fused with the
 // schedule transition that consumes them: one workgroup per candidate slot.
-// UWSPR_FAST_SEARCH=1, stages S0..S4: the per-hypothesis metric by wavefront shuffle-tree sums -- each lane
+// Option "fast_search", stages S0..S4: the per-hypothesis metric by wavefront shuffle-tree sums -- each lane
 // adds its (up to three) symbols' terms, then six butterfly steps; a different summation ORDER than
 // cc:213-215, so the metric agrees with the reference only to rounding (~1e-6 relative).
 __device__ __forceinline__ float wave_sum(float v) {

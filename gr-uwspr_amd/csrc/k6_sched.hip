@@ -8,7 +8,7 @@
 // natural unit is: one 16-wavefront workgroup = one candidate, running
 // S0 -> S5 back to back with no kernel boundary, no tone magnitudes in HBM and
 // no cross-workgroup traffic.  (The staged form -- k4_* + k5_fold_step, 17
-// launches per batch -- stays as UWSPR_SCHED_FUSED=0; both give the same bytes.)
+// launches per batch -- stays as option "sched" = 0; both give the same bytes.)
 //
 // Mapping.  A lane owns a symbol window ("row") and ONE tone, and accumulates
 // inp/quad for several hypotheses of the stage against it, every accumulator

@@ -227,7 +227,7 @@ struct uwspr_ctx {
   size_t cap_need; uint8_t *d_need;   // staging of the resume mask
   int last_slots, last_sched_B, last_sched_per_frame;
   bool last_sched_lazy; uwspr_demod_out *last_sched_out;   // what uwspr_demod_resume may continue (run_schedule)
-  unsigned long long *d_sched_stamps; size_t cap_sched_stamps;   // UWSPR_SCHED_STAMPS=1: phase times of the last launch
+  unsigned long long *d_sched_stamps; size_t cap_sched_stamps;   // option "sched_stamps": phase times of the last launch
   size_t cap_slab; uint8_t *d_slab;
   // multi-GPU gather (dist.hip): RCCL communicator of this rank, or null (single rank / not initialised)
   void *dist_comm; int dist_rank, dist_world;

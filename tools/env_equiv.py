@@ -14,7 +14,7 @@ import gr_uwspr_amd as G  # noqa: E402
 def run(env, frames, maxdrift):
     keep = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
-    os.environ["UWSPR_SCHED_FUSED"] = "0"
+    os.environ.setdefault("UWSPR_OPTIONS", "sched=0")
     c = G.Context(maxdrift=maxdrift)
     try:
         cands, out = c.pipeline_batch(frames, max_per_frame=3)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""UWSPR_FAST_SEARCH=1 against the exact path (the north-star's FMA / shuffle-tree form of
+"""Option fast_search = 1 against the exact path (the north-star's FMA / shuffle-tree form of
 the search stages S0..S4, S5 -- the soft symbols -- stays exact).  Over N frames at mixed SNR, every
 refined candidate: how often the search lands elsewhere (shift1 / f1 / drift1 differ), how far sync1 moves,
 whether the soft symbols still agree where the search agrees, and what changes in the decode set.
@@ -19,11 +19,8 @@ max_rel = 0.0
 rels = []
 worst = None
 t_exact = t_fast = 0.0
-os.environ["UWSPR_SCHED_FUSED"] = "0"
-cx = G.Context()
-os.environ["UWSPR_FAST_SEARCH"] = "1"
-cf = G.Context()
-os.environ.pop("UWSPR_FAST_SEARCH")
+cx = G.Context(options={"sched": 0})
+cf = G.Context(options={"fast_search": 1})
 snrs = (-18.0, -22.0, -25.0, -27.0, -29.0, -31.0, None)
 done = 0
 k = 0

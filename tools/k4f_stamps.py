@@ -7,6 +7,8 @@ import sys
 import numpy as np
 import torch
 sys.path.insert(0, "/root/repo")
+import os
+os.environ.setdefault("UWSPR_OPTIONS", "sched=0")
 import gr_uwspr_amd as G
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import torch
 sys.path.insert(0, "/root/repo")
-os.environ["UWSPR_SCHED_FUSED"] = "0"
+os.environ["UWSPR_OPTIONS"] = os.environ.get("UWSPR_OPTIONS", "sched=0,stage_kernels=2")
 import gr_uwspr_amd as G
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -1,7 +1,7 @@
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, "/root/repo")
-os.environ["UWSPR_SCHED_FUSED"] = "0"
+os.environ["UWSPR_OPTIONS"] = os.environ.get("UWSPR_OPTIONS", "sched=0,stage_kernels=2")
 import gr_uwspr_amd as G
 N = G.native; dev = torch.device("cuda", 0)
 B = 256

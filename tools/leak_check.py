@@ -18,7 +18,7 @@ print("leak check ok")
 # round 3: the same for the stream ring, the staged form's per-slot tables and the pipe (its lanes' contexts, the
 # device ring, the page-locked staging buffers and result buffers, its coordinator threads)
 import os, threading
-os.environ["UWSPR_SCHED_FUSED"] = "0"
+os.environ["UWSPR_OPTIONS"] = "sched=0"
 stream = np.concatenate([fr[k][:10 * 3375] for k in range(12)])
 free0 = None
 for it in range(40):

@@ -1,4 +1,4 @@
-"""Phase times inside the fused schedule kernel (k6_sched): UWSPR_SCHED_STAMPS=1 build-free
+"""Phase times inside the fused schedule kernel (k6_sched): option sched_stamps = 1, build-free
 diagnostic.  Prints the median / max duration of every phase over the candidates of one batch."""
 import ctypes as C
 import os
@@ -6,7 +6,7 @@ import sys
 
 import numpy as np
 
-os.environ["UWSPR_SCHED_STAMPS"] = "1"
+os.environ["UWSPR_OPTIONS"] = "sched=1,sched_stamps=1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import gr_uwspr_amd as G  # noqa: E402

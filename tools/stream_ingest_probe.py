@@ -8,7 +8,7 @@ streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
 for st in streams:
     with torch.cuda.stream(st): torch.zeros(1, device=dev)
 torch.cuda.synchronize()
-os.environ["UWSPR_SCHED_FUSED"] = os.environ.get("FORM", "1")
+os.environ["UWSPR_OPTIONS"] = "sched=" + os.environ.get("FORM", "1")
 frames = G.synth.make_frames(B, seed=1, snr_db=-20.0)
 cc = G.Context(); cc.set_stream(streams[0].cuda_stream)
 cin = G.Context(); cin.set_stream(streams[1].cuda_stream)

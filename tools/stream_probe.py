@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import gr_uwspr_amd as G  # noqa: E402
 
-os.environ["UWSPR_SCHED_FUSED"] = "0"
+os.environ["UWSPR_OPTIONS"] = "sched=0"
 dev = torch.device("cuda", 0)
 B, K, NS = 256, 100, 3
 batches = [G.synth.make_frames_torch(B, dev, seed=0xC0FFEE + 104729 * k, snr_db=-20.0) for k in range(5)]
