@@ -570,7 +570,7 @@ def main():
     stream_leg = None
     if host_legs:
         torch.cuda.synchronize()
-        REP, KS = 5, max(50, min(K, 100))
+        REP, KS = 5, 500      # (round 3's 100-step repeats of these thread-pool + three-lane legs spread by +-19 % on the driver's box)
         by_form = {}
         for form, pipe in pipes_e2e.items():
             try:
@@ -627,8 +627,8 @@ def main():
                 pipe.collect()
                 st0 = pipe.stats()
                 prates = []
-                ks = KS if name == "quiet" else 8
-                for _ in range(REP if name == "quiet" else 2):
+                ks = KS if name == "quiet" else 40
+                for _ in range(REP if name == "quiet" else 3):
                     t2 = time.perf_counter()
                     f0 = pipe.stats()["frames"]
                     for i in range(ks):

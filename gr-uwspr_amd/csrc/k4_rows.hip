@@ -4,32 +4,38 @@
 // Reference: the hot loop of sync_and_demodulate_impl::sync_and_demodulate, cc:167-212 (per-symbol
 // frequency cc:170-183, phasor recurrence cc:186-199, correlation cc:200-211).
 //
-// Why this shape (round 4; tools/issue_probe.hip, tools/k4f_stamps.py):
-//  * a gfx950 wavefront issues a binary32 VALU instruction at best every 4.5 cycles (5.9 alone on its SIMD), whatever
-//    the dependences between its instructions; a SIMD reaches its 1-per-2-cycles rate only from three wavefronts up, and
-//    with the loop's LDS reads mixed in only from four.  The round-3 kernels ran 2 592 wavefronts per launch (2 or 3 per
-//    SIMD, 120 CUs with two workgroups and 136 with three): the two-wavefront SIMDs issued at 0.34 per cycle and the
-//    kernel ended with the third workgroup of the fuller CUs, 11 us after everything else.
-//  * here a launch is 768 workgroups of EQUAL work -- one per (candidate slot, third of its 162 symbols) -- of
-//    4 HS wavefronts: exactly 3 HS wavefronts per SIMD on 256 CUs, all resident from the first cycle to the last.
+// An OPTION ("stage_kernels" = 2), not the default.  It is the balanced shape of the staged form: a launch is 768
+// workgroups of EQUAL work -- one per (candidate slot, third of its 162 symbols) -- of 4 HS wavefronts, exactly 3 per
+// CU, all resident from the first cycle to the last (the packed kernels of k4_tonecorr.hip put two workgroups on 120
+// CUs and three on 136).  On one HIP stream it is the faster form (K4 0.317 ms per 256-frame step against 0.332); under
+// three streams it is the slower one (653 k frames/s against 712 k): it fills every CU by itself, and 54 of 64 lanes
+// carry a symbol.  What was measured on the way (profiles/r04_*): a wavefront issues a binary32
+// VALU instruction at best every 4.5 cycles whatever the dependences between its instructions; equal priorities are
+// served oldest first, so of three equal workgroups on a CU the last dispatched finishes 15 us after the first -- hence
+// the priority rotation in chunk_turn(); with the phasors fetched by scalar loads a wavefront is bound by their latency
+// (590 cycles per 64-instruction block, one block ahead is not enough) and a CU by the scalar path's one load per ~40
+// cycles; through LDS the kernel sits where every K4 form sits, at ~0.6 of the VALU issue rate with the LDS array ~70 %
+// busy; removing its arithmetic leaves 25 of S0's 44 us (loader + barriers), cache-resident samples change nothing.
 //
-// Mapping.  Workgroup = (slot, third): symbols 54 t .. 54 t + 53, one per LANE (54 of 64 lanes; lane 54 of the last
-// third carries S0's virtual 163rd row).  Wavefront w = tone (w & 3) x hypothesis subset (w >> 2): a lane accumulates
-// inp / quad of its symbol window against ONE tone for the subset's hypotheses, every accumulator seeing exactly the
-// reference's sequence of binary32 operations (cc:206-207: no FMA, no tree).
+// Mapping.  Workgroup = (slot, third): symbols 54 t .. 54 t + 53, one per LANE (lane 54 of the last third carries S0's
+// virtual 163rd row).  Wavefront w = tone (w & 3) x hypothesis subset (w >> 2): a lane accumulates inp / quad of its
+// symbol window against ONE tone for the subset's hypotheses, every accumulator seeing exactly the reference's sequence
+// of binary32 operations (cc:206-207: no FMA, no tree).
 //  * Samples, sample-major: the workgroup streams its rows [L0 + 256 i, L0 + 256 i + 256 + span) through a
 //    double-buffered LDS image, 32 samples per row and chunk (coalesced 8-byte loads; cc:205's n > 0 && n < np test is
 //    applied by the loader: a skipped sample is a zero, which leaves inp / quad unchanged), one barrier per chunk.  A
 //    hypothesis whose lag is L0 + D sees stream position a as its sample k = a - D: the lag sweeps (S0: 4 lags 64
-//    apart, S3: 5 lags 16 apart, S5: 17 lags 8 apart) are ONE pass over the rows, nothing is loaded per lag.
+//    apart, S3: 5 lags 16 apart, S5: 17 lags 8 apart) are ONE pass over the rows, nothing is loaded per lag.  Which
+//    hypotheses are inside their windows at a stream position is compile time (phases: rows_make_phases).
 //  * Phasors.  When the per-symbol frequency does not depend on the symbol (drift 0 or the straight-line model with
 //    t = 0: the reference's `fplast` cache hits for the same reason, cc:185) the sequence c[k], s[k] of cc:186-199 is a
 //    table per (frequency, tone), built once per slot by the schedule kernels (k5_fold_schedule.hip: ptab_build; set A
-//    around the candidate frequency for S0 / S1, set B around the S2 result for S3 / S4 / S5).  Slot and tone are
-//    wavefront-uniform here, so a wavefront fetches 8 steps with one SCALAR load (s_load_dwordx16) and uses them as
-//    SGPR operands: the walk is 8 VALU instructions per sample and hypothesis and one ds_read_b128 per two samples,
-//    nothing else.  With a per-symbol frequency (a drifting linear model) every lane runs its own recurrences
-//    (cc:193-195), 14 instructions per sample and hypothesis -- same kernel, workgroup-uniform branch.
+//    around the candidate frequency for S0 / S1, set B around the S2 result for S3 / S4 / S5).  The workgroup copies
+//    the chunk's slices (frequency stages) or the whole table (lag stages) into an LDS image with vector loads; a lane
+//    reads two steps per ds_read_b128 (the same address in every lane: broadcast).  Stage 5 (17 lags) keeps the
+//    generic walk with scalar loads (its phased code would be 50 KB).  With a per-symbol frequency (a drifting linear
+//    model) every lane runs its own recurrences (cc:193-195), 14 instructions per sample and hypothesis -- same
+//    kernel, workgroup-uniform branch.
 //  * S0's fifth lag is its first one symbol later: (lag 4, symbol i) is (lag 0, symbol i + 1) whenever the frequency
 //    does not depend on the symbol; lane 54 of the last third walks a virtual symbol 162 for (lag 4, symbol 161).
 #include <type_traits>
@@ -46,7 +52,6 @@ constexpr int KR_CH = 32;                    // samples per row and staged chunk
 constexpr int KR_ROWDW = 2 * KR_CH + 4;      // dwords per staged row: 32 samples x 8 B + 16 B pad (conflict-free b128 column reads)
 
 typedef float kr_f16 __attribute__((ext_vector_type(16)));
-typedef float kr_f4 __attribute__((ext_vector_type(4)));
 #define KR_CONST __attribute__((address_space(4)))
 
 // The stages as compile-time geometry.  Hypothesis h of a stage has lag L0 + 8 dk8(h); NH hypotheses per slot.
