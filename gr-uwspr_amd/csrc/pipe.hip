@@ -455,7 +455,7 @@ extern "C" int uwspr_pipe_open(const uwspr_params *p, int device, const uwspr_pi
     L.dec.resize((size_t)Bm * per); L.idt.resize((size_t)Bm * per); L.msg.resize((size_t)Bm * per * 7);
   }
   // pushed streams: the device ring and the page-locked staging buffers are made by the first acquire (open_ingest):
-  // a pipe that only takes device frames (uwspr_pipe_submit_device) never pays their 2.2 GB + 0.37 GB (defaults)
+  // a pipe that only takes device frames (uwspr_pipe_submit_device) never pays their 2 x 83 MB of HBM + 4 x 6.9 MB page-locked (hop 3375; 2.2 GB + 0.37 GB at hop 0 = the frame length)
   q->stage_samples = (size_t)Bm * q->o.hop;
   if (q->o.host_threads <= 0) q->o.host_threads = host_cpu_share() > 3 ? host_cpu_share() - 2 : 1;
   q->pool = &host_pool::shared();   // the process-wide pool; this pipe's jobs use host_threads of it
