@@ -15,6 +15,26 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Equal-priority wavefronts are served oldest first: of the workgroups b, b + 256, b + 512 that the
+// dispatcher puts on one CU, the youngest is starved while the others run and then finishes alone, two wavefronts on
+// each SIMD.  Rotating the issue priority over the three from chunk to chunk lets them finish together.  `turn` counts
+// the chunks; the class is the position of the workgroup in its CU's queue.  (s_setprio takes an immediate.)
+// Used by k4_fpack (k4_rows.hip rotates the same way every fourth chunk).  In k4_lag0 and k4_ring it bought < 1 % alone and cost 0.1-0.3 % of the three-stream
+// rate (profiles/r04_prio_rotation_ab.txt), so they stay at the default priority.
+#ifndef UWSPR_K4_PRIO_ROTATION
+#define UWSPR_K4_PRIO_ROTATION 1
+#endif
+__device__ __forceinline__ unsigned k4_prio_class() { return (blockIdx.x >> 8) % 3u; }
+__device__ __forceinline__ void k4_rotate_priority(unsigned turn, unsigned prio_class) {
+#if UWSPR_K4_PRIO_ROTATION
+  switch ((turn + prio_class) % 3u) {   // wavefront-uniform
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    default: __builtin_amdgcn_s_setprio(2); break;
+  }
+#endif
+}
+
 // The correlation step (cc:206-207) and the phasor rotation (cc:193-195).  FAST = false is the
 // reference's arithmetic: every product and every sum rounded on its own, left to right.  FAST = true
 // (the fast-search option, stages S0..S4 only, never the soft symbols) contracts them into fused

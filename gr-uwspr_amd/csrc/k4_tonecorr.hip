@@ -748,6 +748,7 @@ __global__ __launch_bounds__(256) void k4_fpack(
   const long long total = (long long)nslots * UWSPR_NSYM;
   const long long g0 = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * ROWS;
   if (g0 >= total) return;  // workgroup-uniform
+  const unsigned prio_class = k4_prio_class();
 
   const int slotA = (int)(g0 / UWSPR_NSYM);
   const int iA0 = (int)(g0 - (long long)slotA * UWSPR_NSYM);
@@ -863,6 +864,7 @@ __global__ __launch_bounds__(256) void k4_fpack(
         K4F_T(t2);
         __syncthreads();
         K4F_T(t3);
+        k4_rotate_priority((unsigned)ch, prio_class);
         load_chunk(min(ch + 1, NCH - 1));  // in flight during the arithmetic (no branch around it)
 #pragma unroll
         for (int k = 0; k < CH; k += 2) {
