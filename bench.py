@@ -477,8 +477,10 @@ def main():
     reuse_on = ctx.get_option("reuse") != 0
     fine_corr = fine_hyps - ((nlive + 3 * nworth) if reuse_on else 0) - nlive
     # binary32 operations those correlations need: 8 per sample, tone and hypothesis; the per-symbol
-    # phasor recurrences (6) only where the algorithm cannot share them (the two drift tries of S2)
-    ops_step = float(fine_corr) * OPS_MAC + 2.0 * nlin * OPS_PHASOR
+    # phasor recurrences (6) only where the algorithm cannot share them: the two drift tries of S2, and since round 4
+    # ONE recurrence per mirrored symbol pair of the two (k4_pair.hip: 163 pair-rows for 2 x 162 symbols; the candidates
+    # of this workload come from an FDR with maxdrift = 0, so every linear one is mirrored)
+    ops_step = float(fine_corr) * OPS_MAC + (163.0 / 162.0) * nlin * OPS_PHASOR
 
     # host tail alone: de-interleave + Fano on the persistent pool (all the cores this process may use),
     # one call per 256-record batch as the pipeline makes them
@@ -725,7 +727,8 @@ def main():
                          "accounting": "single stream, HIP events in the kernel's own dispatch packet, steps over "
                                        "%d distinct batches; ops = 8 per sample, tone and hypothesis of the "
                                        "correlations the launches run (config.fine_correlations_run_per_step) + 6 "
-                                       "for the per-symbol phasors of S2's two drift tries" % nb,
+                                       "for the per-symbol phasors of S2's two drift tries, one recurrence per "
+                                       "mirrored symbol pair (the count of rounds 2-3 was two: 2.1 %% more ops)" % nb,
                          "north_star_algorithmic": {
                              "effective_sample_rate_GBs": eff_gbs, "x_hbm_peak": eff_gbs / HBM_PEAK_GBS,
                              "note": "331950 B per correlation as if every hypothesis streamed its symbol windows "

@@ -80,4 +80,12 @@ __device__ __forceinline__ void k4_tone_step(float fp, int tone, float &cd, floa
   sd = (float)sn;
 }
 
+// Stage S2's two tries of a slot (hyps 2 s: drift1 + 0.5, 2 s + 1: drift1 - 0.5; cc:425, 429) mirror each other when
+// the candidate had no drift: same frame, lag and f0, opposite drifts.  Then symbol i of the first has, bit for bit,
+// the tone frequency of symbol 162 - i of the second (k4_pair.hip), and k4_dpair computes both with one recurrence.
+__device__ __forceinline__ bool k4_drift_pair(const dev_hyp &p, const dev_hyp &m, int nframes) {
+  return p.frame >= 0 && p.frame < nframes && m.frame == p.frame && p.m_type == UWSPR_LINEAR && m.m_type == UWSPR_LINEAR &&
+         p.lag == m.lag && __float_as_uint(p.f0) == __float_as_uint(m.f0) && p.drift == -m.drift;
+}
+
 }  // namespace uwspr

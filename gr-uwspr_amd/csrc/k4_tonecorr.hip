@@ -46,7 +46,8 @@ constexpr int K4_ROWDW = 36;  // dwords per staged row: 16 samples x 8 B + 16 B 
 template <int T, bool FAST = false>
 __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
     const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_hyp *__restrict__ hyps,
-    int H, float *__restrict__ p_out, const dev_grp *__restrict__ taken, int hyps_per_grp) {
+    int H, float *__restrict__ p_out, const dev_grp *__restrict__ taken, int hyps_per_grp, int skip_pairs) {
+  // skip_pairs: stage S2, two tries per slot -- the slots k4_dpair computes (k4_drift_pair) are left alone here.
   // taken (or null): hypothesis h belongs to group h / hyps_per_grp; groups that have their phasor table
   // (dev_grp::nvalid bits 16..23) were computed by another kernel (k4_lag0) -- left alone here, nothing stored
   constexpr int PPW = 16 * T;        // pairs per wavefront
@@ -68,8 +69,11 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
   const int sb = min(PPW, UWSPR_NSYM - iA0);  // pairs < sb belong to hA
   dev_hyp A = hyps[hA];
   dev_hyp Bh = hyps[min(hA + 1, H - 1)];
-  const bool takenA = taken && ((taken[hA / hyps_per_grp].nvalid >> 16) & 0xff) != 0;
-  const bool takenB = taken && ((taken[min(hA + 1, H - 1) / hyps_per_grp].nvalid >> 16) & 0xff) != 0;
+  const int hB = min(hA + 1, H - 1);
+  const bool takenA = (taken && ((taken[hA / hyps_per_grp].nvalid >> 16) & 0xff) != 0) ||
+                      (skip_pairs && k4_drift_pair(hyps[hA & ~1], hyps[hA | 1], nframes));
+  const bool takenB = (taken && ((taken[hB / hyps_per_grp].nvalid >> 16) & 0xff) != 0) ||
+                      (skip_pairs && k4_drift_pair(hyps[hB & ~1], hyps[hB | 1], nframes));
   const bool okA = A.frame >= 0 && A.frame < nframes && !takenA;
   const bool okB = (hA + 1 < H) && Bh.frame >= 0 && Bh.frame < nframes && !takenB;
   // hypotheses that are skipped still own LDS rows: point them at safe samples
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(64 * K4_WAVES) void k4_tonecorr(
 }
 
 void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int H,
-                     float4 *p, const dev_grp *taken, int hyps_per_grp) {
+                     float4 *p, const dev_grp *taken, int hyps_per_grp, bool skip_pairs) {
   if (H <= 0) return;
   prof_scope ps(c, UWSPR_K_TONECORR, H, true);
   const long long total = (long long)H * UWSPR_NSYM;
@@ -208,10 +212,11 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
   float *po = (float *)p;
   dim3 blk(64 * K4_WAVES);
   if (hyps_per_grp < 1) hyps_per_grp = 1;
-  if (T == 1 && c->fast_now) launch_timed(c, ps, (k4_tonecorr<1, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po, taken, hyps_per_grp);
-  else if (T == 1) launch_timed(c, ps, k4_tonecorr<1>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po, taken, hyps_per_grp);
-  else if (T == 2) launch_timed(c, ps, k4_tonecorr<2>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po, taken, hyps_per_grp);
-  else launch_timed(c, ps, k4_tonecorr<4>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po, taken, hyps_per_grp);
+  const int sp = skip_pairs && (H % 2 == 0) ? 1 : 0;
+  if (T == 1 && c->fast_now) launch_timed(c, ps, (k4_tonecorr<1, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po, taken, hyps_per_grp, sp);
+  else if (T == 1) launch_timed(c, ps, k4_tonecorr<1>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po, taken, hyps_per_grp, sp);
+  else if (T == 2) launch_timed(c, ps, k4_tonecorr<2>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po, taken, hyps_per_grp, sp);
+  else launch_timed(c, ps, k4_tonecorr<4>, dim3(blocks), blk, 0, fr, c->fstride, c->np, B, hyps, H, po, taken, hyps_per_grp, sp);
 }
 
 }  // namespace uwspr

@@ -834,7 +834,7 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
   launch_sched_init(c, dcands, dnpk, cand_stride, B, per_frame);
   const bool lazy = njig < UWSPR_NJIG;   // only tries idt < njig of stage 5, packed njig per slot
   // Staged form, "stage_kernels": 1 (default) = S0 sample-major on packed rows (k4_lag0), S1 / S4 packed frequency stage
-  // (k4_fpack), S3 / S5 LDS ring (k4_ring), S2 flat; 2 = the rows form (k4_rows.hip) for the stage kinds of "rows_mask";
+  // (k4_fpack), S3 / S5 LDS ring (k4_ring), S2 mirrored pairs (k4_dpair); 2 = the rows form (k4_rows.hip) for the stage kinds of "rows_mask";
   // 0 = the flat kernel for every stage (the independent reference form of the equivalence tests).
   static const int rows_kind[6] = {UWSPR_ROWS_S0, UWSPR_ROWS_S1, -1, UWSPR_ROWS_S3, UWSPR_ROWS_S4, UWSPR_ROWS_S5};
   const int sk = c->opt[UWSPR_OPT_STAGE_KERNELS];
@@ -843,7 +843,18 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
     const int H = (int)(nslots * (s == 5 ? njig : hpc[s]));
     const dev_hyp *h = half[s & 1];
     const bool rows = sk == 2 && c->use_ptab && s != 2 && ((c->opt[UWSPR_OPT_ROWS_MASK] >> rows_kind[s]) & 1);
-    if (sk == 0 || s == 2 || (lazy && s == 5)) launch_tonecorr(c, dframes, B, h, H, c->d_p);   // (lazy S5: few, unrelated lags)
+    if (sk == 0 || (lazy && s == 5)) launch_tonecorr(c, dframes, B, h, H, c->d_p);   // (lazy S5: few, unrelated lags)
+#if !defined(UWSPR_S2_PAIRS) || UWSPR_S2_PAIRS   // (0: experiment builds, the flat kernel as before)
+    else if (s == 2) {
+      // S2: candidates that came in without drift have mirrored tries: one phasor recurrence for both (k4_pair.hip);
+      // the others through the flat kernel, which leaves the former alone -- not needed after this context's own FDR
+      // with maxdrift = 0
+      launch_tonecorr_dpair(c, dframes, B, h, (int)nslots, c->d_p);
+      if (!(c->cands_from_fdr && c->p.maxdrift == 0)) launch_tonecorr(c, dframes, B, h, H, c->d_p, nullptr, 1, true);
+    }
+#else
+    else if (s == 2) launch_tonecorr(c, dframes, B, h, H, c->d_p);
+#endif
     else if (rows) launch_tonecorr_rows(c, dframes, B, rows_kind[s], h, (int)nslots, H, c->d_p);
     else if (s == 1 || s == 4) launch_tonecorr_fstage(c, dframes, B, h, (int)nslots, H, c->d_p);
     else if (s == 3) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)nslots, 5, 16, H, c->d_p, 1);

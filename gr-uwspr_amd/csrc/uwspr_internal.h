@@ -246,9 +246,12 @@ void launch_spectrogram(uwspr_ctx *c, const float *frames, int B);
 void launch_spectrum(uwspr_ctx *c, int B);
 void launch_coarse(uwspr_ctx *c, int B);
 void launch_prep_hyps(uwspr_ctx *c, const uwspr_hyp *abi, dev_hyp *out, int H);
-// flat form; taken != null: hypotheses of groups that have their phasor table are left alone (see k4_tonecorr)
+// flat form; taken != null: hypotheses of groups that have their phasor table are left alone (see k4_tonecorr);
+// skip_pairs: stage S2 -- the mirrored drift tries launch_tonecorr_dpair computes are left alone
 void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int H,
-                     float4 *p, const dev_grp *taken = nullptr, int hyps_per_grp = 1);
+                     float4 *p, const dev_grp *taken = nullptr, int hyps_per_grp = 1, bool skip_pairs = false);
+// stage S2 (hyps 2 s, 2 s + 1 = the two drift tries of slot s): the slots whose tries mirror each other (k4_pair.hip)
+void launch_tonecorr_dpair(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int nslots, float4 *p);
 void launch_tonecorr_lag0(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int nslots,
                           int64_t nhyps, float4 *p);
 void launch_tonecorr_rows(uwspr_ctx *c, const float *frames, int B, int kind, const dev_hyp *hyps, int nslots,
