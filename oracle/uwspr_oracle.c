@@ -532,3 +532,19 @@ void orc_demod_candidate(const orc_candidate *cand_in, int cf, const float *id,
     out->jig_rms[idt] = orc_symbols_rms(out->symbols[idt]);
   }
 }
+
+/* test support: see uwspr_oracle.h */
+long orc_log10_gap(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride, uint32_t *first_bad) {
+  long bad = 0;
+  if (stride == 0) stride = 1;
+  for (uint64_t b = lo_bits; b < hi_bits; b += stride) {
+    uint32_t u = (uint32_t)b, ga, gb;
+    float x, a, c;
+    memcpy(&x, &u, 4);
+    a = (float)10 * log10f(x);                      /* the oracle's (and g++'s) form of cc:303 */
+    c = 10.0f * (float)log10((double)x);            /* k2_spectrum.hip */
+    memcpy(&ga, &a, 4); memcpy(&gb, &c, 4);
+    if (ga != gb) { if (!bad && first_bad) *first_bad = u; bad++; }
+  }
+  return bad;
+}

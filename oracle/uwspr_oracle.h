@@ -131,6 +131,11 @@ void orc_demod_candidate(const orc_candidate *cand, int cf, const float *id,
 /* sync_and_demodulate_impl.cc:469-474 */
 float orc_symbols_rms(const unsigned char *symbols);
 
+/* Test support for FDR_impl.cc:303 (`10*log10(smspec)`, the binary32 overload): over the binary32 values with bit
+ * patterns lo_bits <= b < hi_bits (step `stride`), how many give  log10f(x) != (float)log10((double)x)  -- this libm's
+ * log10f against the binary64 route the HIP kernel takes (k2_spectrum.hip).  *first_bad = the first such pattern. */
+long orc_log10_gap(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride, uint32_t *first_bad);
+
 #ifdef __cplusplus
 }
 #endif
