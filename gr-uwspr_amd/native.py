@@ -48,13 +48,6 @@ def _hipcc():
     raise UwsprError(-4, "hipcc not found")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
-
-
 def _digest(paths):
     """Content hash of the build inputs: what decides whether the library is current (file
     times do not survive a copy to another machine; contents do)."""
@@ -78,33 +71,58 @@ def source_digest():
 
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 every kernel + the C ABI into lib/libuwspr_hip.so,
-    then the host block mirror (gr-uwspr_amd/host) into lib/libuwspr_blocks.so."""
+    then the host block mirror (gr-uwspr_amd/host) into lib/libuwspr_blocks.so.
+
+    Safe to call from several processes at once (one rank per GPU importing the package at the same moment): the
+    check and the build run under a file lock, a build goes to a temporary file that is renamed into place, and
+    what decides "current" is the flags + the CONTENTS of the sources (a stamp next to the library) -- not file
+    times and not the directory the tree happens to live in, neither of which survives the copy to a GPU box."""
+    import fcntl
     os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     deps.append(os.path.join(_HERE, "..", "include", "uwspr_hip.h"))
     extra = _EXTRA   # experiments only (separate output file, see LIBPATH)
-    cmd = [_hipcc()] + HIPFLAGS + extra + ["-shared", "-pthread"] + srcs + ["-ldl", "-o", LIBPATH]
-    stamp = LIBPATH + ".cmd"
-    want = " ".join(cmd) + "\n" + _digest(deps)
-    same = os.path.exists(LIBPATH) and os.path.exists(stamp) and open(stamp).read() == want
-    if force or not same:
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
-        open(stamp, "w").write(want)
+    flags = HIPFLAGS + extra + ["-shared", "-pthread"]
     hostdir = os.path.join(_HERE, "host")
     hsrcs = [os.path.join(hostdir, f) for f in sorted(os.listdir(hostdir)) if f.endswith(".cc")] \
         if os.path.isdir(hostdir) else []
-    if hsrcs:
-        hdeps = hsrcs + [os.path.join(hostdir, f) for f in os.listdir(hostdir) if f.endswith(".h")]
-        if not extra and (force or _stale(HOSTLIB, hdeps + [LIBPATH])):
-            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I" + hostdir,
-                   "-I" + os.path.join(_HERE, "..", "include")] + hsrcs + \
-                  ["-o", HOSTLIB, "-L" + LIBDIR, "-luwspr_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+    hdeps = hsrcs + ([os.path.join(hostdir, f) for f in os.listdir(hostdir) if f.endswith(".h")] if hsrcs else [])
+    hflags = ["-O2", "-std=c++17", "-fPIC", "-shared", "-Wall"]
+
+    def atomically(cmd, out):
+        tmp = "%s.tmp%d" % (out, os.getpid())
+        try:
             if verbose:
-                print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+                print(" ".join(cmd + ["-o", out]))
+            subprocess.run(cmd + ["-o", tmp], check=True)
+            os.replace(tmp, out)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+
+    def current(out, want):
+        stamp = out + ".cmd"
+        return os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == want
+
+    def stamp(out, want):
+        tmp = "%s.cmd.tmp%d" % (out, os.getpid())
+        with open(tmp, "w") as f:
+            f.write(want)
+        os.replace(tmp, out + ".cmd")
+
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)     # (released when the file is closed)
+        want = " ".join(flags + [os.path.basename(q) for q in srcs]) + "\n" + _digest(deps)
+        if force or not current(LIBPATH, want):
+            atomically([_hipcc()] + flags + srcs + ["-ldl"], LIBPATH)
+            stamp(LIBPATH, want)
+        if hsrcs and not extra:
+            hwant = " ".join(hflags + [os.path.basename(q) for q in hsrcs]) + "\n" + _digest(hdeps + deps)
+            if force or not current(HOSTLIB, hwant):
+                atomically(["g++"] + hflags + ["-I" + hostdir, "-I" + os.path.join(_HERE, "..", "include")] + hsrcs +
+                           ["-L" + LIBDIR, "-luwspr_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"], HOSTLIB)
+                stamp(HOSTLIB, hwant)
     return LIBPATH
 
 

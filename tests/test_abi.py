@@ -64,3 +64,27 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"oracle_py|uwspr_oracle|liboracle|libuwspr_ref", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_build_is_shared_by_ranks_and_independent_of_the_tree_path(G, tmp_path):
+    """What the driver's multi-GPU launch does: N ranks import the package at the same moment, from whatever path the
+    tree was copied to.  The library that travelled with the tree must be taken as it is -- no rank recompiles it
+    (the stamp holds flags + source contents, not paths or file times), and concurrent callers neither race for the
+    output file nor block each other for longer than the check."""
+    import subprocess
+    import sys
+    N = G.native
+    N.build()
+    before = (os.path.getmtime(N.LIBPATH), os.path.getsize(N.LIBPATH))
+    repo = os.path.abspath(os.path.join(os.path.dirname(N.CSRC), ".."))
+    other = tmp_path / "another_root"
+    os.symlink(repo, other)                               # the same tree under another absolute path
+    code = ("import sys, time; sys.path.insert(0, %r); t = time.time(); import gr_uwspr_amd as G; G.build(); "
+            "L = G.native.lib(); assert hasattr(L, 'uwspr_ctx_create'); print('%%.1f' %% (time.time() - t))" % str(other))
+    procs = [subprocess.Popen([sys.executable, "-c", code], cwd=str(other), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for _ in range(4)]
+    for p in procs:
+        out, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err[-2000:]
+        assert float(out.strip().splitlines()[-1]) < 60.0, out       # (an import, not a compile)
+    assert (os.path.getmtime(N.LIBPATH), os.path.getsize(N.LIBPATH)) == before
