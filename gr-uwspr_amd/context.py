@@ -591,6 +591,10 @@ class Pipe:
         """test hook: batch number `batch` fails at its launch (where = 0) or in its host tail (where = 1)"""
         self._chk(self.L.uwspr_pipe_inject_failure(self.h, int(batch), int(where)))
 
+    def set_option(self, name, value):
+        """uwspr_pipe_set_option: an option of every lane's context; only while nothing is in flight"""
+        self._chk(self.L.uwspr_pipe_set_option(self.h, name.encode(), int(value)))
+
     def stats(self):
         st = N.PipeStats()
         self._chk(self.L.uwspr_pipe_get_stats(self.h, C.byref(st)))

@@ -551,6 +551,24 @@ extern "C" int uwspr_pipe_submit_device(uwspr_pipe *q, const float *dev_frames, 
   return rc;
 }
 
+// An option of every lane's context (uwspr_set_option).  Only while nothing is in flight -- the lanes read their
+// options when they launch -- and not "sched": the pipe picks the schedule form by its lane count (opts.sched_form).
+extern "C" int uwspr_pipe_set_option(uwspr_pipe *q, const char *name, int value) {
+  if (!q || !name) return UWSPR_ERR_ARG;
+  if (const int f = q->failed.load()) return f;
+  if (!strcmp(name, "sched")) return parg(q, "uwspr_pipe_set_option: \"sched\" belongs to uwspr_pipe_opts.sched_form");
+  {
+    std::lock_guard<std::mutex> lk(q->m);
+    for (auto &L : q->lanes)
+      if (L.busy) { snprintf(q->err, sizeof(q->err), "uwspr_pipe_set_option(%s): batches in flight (flush first)", name); return UWSPR_ERR_ARG; }
+  }
+  for (auto &L : q->lanes) {
+    const int rc = uwspr_set_option(L.ctx, name, value);
+    if (rc) return parg(q, "uwspr_pipe_set_option(%s, %d): %s", name, value, uwspr_last_error(L.ctx));
+  }
+  return UWSPR_OK;
+}
+
 extern "C" int uwspr_pipe_flush(uwspr_pipe *q) {
   if (!q) return UWSPR_ERR_ARG;
   (void)hipSetDevice(q->device);

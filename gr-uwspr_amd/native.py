@@ -202,7 +202,7 @@ ABI_SYMBOLS = [
     "uwspr_dist_unique_id", "uwspr_dist_init", "uwspr_dist_gather", "uwspr_dist_finalize",
     "uwspr_pipe_open", "uwspr_pipe_close", "uwspr_pipe_last_error", "uwspr_pipe_acquire", "uwspr_pipe_commit",
     "uwspr_pipe_push", "uwspr_pipe_submit_device", "uwspr_pipe_flush", "uwspr_pipe_collect", "uwspr_pipe_get_stats",
-    "uwspr_pipe_inject_failure",
+    "uwspr_pipe_inject_failure", "uwspr_pipe_set_option",
 ]
 
 _lib = None
@@ -302,5 +302,6 @@ def lib():
     L.uwspr_pipe_collect.argtypes = [vp, vp, ip, ip]
     L.uwspr_pipe_get_stats.argtypes = [vp, C.POINTER(PipeStats)]
     L.uwspr_pipe_inject_failure.argtypes = [vp, C.c_longlong, ip]
+    L.uwspr_pipe_set_option.argtypes = [vp, C.c_char_p, ip]
     _lib = L
     return L

@@ -417,6 +417,10 @@ int uwspr_pipe_flush(uwspr_pipe *pipe);
  * in flight.  returns the count (>= 0) or a negative status. */
 int uwspr_pipe_collect(uwspr_pipe *pipe, uwspr_decode *out, int cap, int wait);
 int uwspr_pipe_get_stats(uwspr_pipe *pipe, uwspr_pipe_stats *st);
+/* uwspr_set_option on every lane's context (e.g. "fast_search").  Only while nothing is in flight (after
+ * uwspr_pipe_flush / before the first batch): UWSPR_ERR_ARG otherwise, and for "sched", which the pipe chooses by its
+ * lane count (uwspr_pipe_opts.sched_form). */
+int uwspr_pipe_set_option(uwspr_pipe *pipe, const char *name, int value);
 /* Error behaviour.  An argument error (too many samples, a bad B or stride) fails THAT call with UWSPR_ERR_ARG and
  * its message; the pipe goes on.  A runtime failure (HIP, a lane's context) is sticky: the batch it hit emits
  * nothing, records of the batches before it stay collectable, every later call -- and uwspr_pipe_collect once

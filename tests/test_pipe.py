@@ -232,3 +232,41 @@ def test_pipe_stream_longer_than_the_device_ring(G):
     assert (recs["stream_pos"] == recs["frame"] * hop).all()
     assert _as_dict(recs) == exp
     assert st["resumed"] >= 1 and st["decoded"] >= 10
+
+
+@pytest.mark.gpu
+def test_pipe_options_reach_every_lane(G):
+    """uwspr_pipe_set_option: fast_search through the pipe (staged lanes) keeps every decision and message of the exact
+    pipe on the same frames (what the option promises: tests/test_gpu_fast_search.py); it is refused while batches are
+    in flight and for "sched", and an unknown name is an argument error that leaves the pipe usable."""
+    import torch
+    frames = _mixed_frames(G, 8, seed=6161)                  # 32 frames
+    dev = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+
+    def run(fast):
+        pipe = G.Pipe(batch_frames=16, max_per_frame=1, lanes=3, sched="staged")
+        try:
+            if fast:
+                pipe.set_option("fast_search", 1)
+            with pytest.raises(G.UwsprError):
+                pipe.set_option("sched", 1)
+            with pytest.raises(G.UwsprError):
+                pipe.set_option("no_such_option", 1)
+            pipe.submit_device(dev[:16])
+            pipe.submit_device(dev[16:])
+            pipe.flush()
+            recs = pipe.collect()
+            pipe.set_option("reuse", 1)                      # nothing in flight any more: accepted
+            return recs
+        finally:
+            pipe.close()
+
+    exact, fast = run(False), run(True)
+    assert len(exact) == len(fast) > 20
+    for k in ("frame", "cand", "npk", "shift1", "worth_a_try", "decoded", "idt"):
+        assert (exact[k] == fast[k]).all(), k
+    assert exact["message"].tobytes() == fast["message"].tobytes()
+    assert exact["f1"].tobytes() == fast["f1"].tobytes() and exact["drift1"].tobytes() == fast["drift1"].tobytes()
+    assert np.all(np.abs(fast["sync1"] - exact["sync1"]) <= 1e-5 * np.maximum(np.abs(exact["sync1"]), 0.1))
+    assert int(exact["decoded"].sum()) >= 8
