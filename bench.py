@@ -45,6 +45,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 committed PMC pass.
   cpu_baseline  the CPU restatement (oracle/, kind "port") on a bounded sample.
   fast_search   `value`'s timed region with option fast_search = 1 (FMA + shuffle-tree stages; never `value`).
+  end_to_end_decoded  uwspr_pipe_*: decoded frames/s on the host, frames in HBM (its `fast_search`: the same leg with the
+                option set on every lane through uwspr_pipe_set_option).
   configs3_n1   BASELINE configs[3] (65 536 frames) on this one GPU: the strong-scaling reference point.
   kernels       HIP-event time per kernel family per step (single stream).
   lazy_s5       the same step with uwspr_set_tries(1): only the first jiggered shift.
@@ -591,6 +593,19 @@ def main():
                     pipe.collect()
                     prates.append(KS * B / (time.perf_counter() - t2))
                 st = pipe.stats()
+                frates = []
+                if form == "staged":      # the same leg with the fast_search option on every lane (NOT the reference's arithmetic)
+                    pipe.set_option("fast_search", 1)
+                    for _ in range(3):
+                        t2 = time.perf_counter()
+                        for i in range(KS):
+                            pipe.submit_device(batches[i % nb], B)
+                            if i % 8 == 7:
+                                pipe.collect()
+                        pipe.flush()
+                        pipe.collect()
+                        frates.append(KS * B / (time.perf_counter() - t2))
+                    st_fast = pipe.stats()
             finally:
                 pipe.close()
             by_form[form] = {"frames_per_s": float(np.median(prates)), "min": min(prates), "max": max(prates),
@@ -599,8 +614,13 @@ def main():
                              "fano_calls_per_frame": st["fano_calls"] / max(st["frames"], 1),
                              "fano_timeouts_per_frame": st["fano_timeouts"] / max(st["frames"], 1),
                              "coordinator_s": {k: st[k] for k in ("gpu_wait_s", "fano_s", "resume_s")}}
+            if frates:
+                by_form[form]["fast_search"] = {"frames_per_s": float(np.median(frates)), "min": min(frates), "max": max(frates),
+                                                "decoded_fraction": (st_fast["decoded"] - st["decoded"]) / max(st_fast["candidates"] - st["candidates"], 1)}
         best = max(by_form, key=lambda f: by_form[f]["frames_per_s"])
         e2e = dict(by_form[best])
+        if "fast_search" not in e2e and "fast_search" in by_form.get("staged", {}):
+            e2e["fast_search"] = by_form["staged"]["fast_search"]
         e2e.update({"sched": best, "by_sched": {f: v["frames_per_s"] for f, v in by_form.items()}, "repeats": REP,
                     "steps_per_repeat": KS, "frames_per_step": B, "lanes": "library default: 3 streams + 6 spare lanes (opened only under long host tails)", "host_threads": max(1, G.host_threads() - 2),
                     "what": "uwspr_pipe_submit_device: frames resident in HBM (the same rotating batches as `value`), "
