@@ -28,7 +28,9 @@
 extern "C" {
 #endif
 
-#define UWSPR_ABI_VERSION 2   /* 2: frame stride, in-place stream views, uwspr_pipe_*, uwspr_dist_*, uwspr_host_threads */
+#define UWSPR_ABI_VERSION 3   /* 2: frame stride, in-place stream views, uwspr_pipe_*, uwspr_dist_*, uwspr_host_threads;
+                                 3: uwspr_set_option / uwspr_get_option, uwspr_pipe_set_option, uwspr_pipe_inject_failure,
+                                    uwspr_pipe_opts.spare_after_us (was reserved) */
 
 typedef enum {
   UWSPR_OK = 0,
