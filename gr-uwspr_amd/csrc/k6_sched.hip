@@ -335,15 +335,83 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int np, int 
     }
   };
 
+  // ---- S2 when its two tries mirror each other (drm == -drp: the candidate came in without drift): symbol i of the
+  // + try and symbol 162 - i of the - try have, bit for bit, the same tone frequency (k4_pair.hip has the argument), so
+  // one recurrence serves both.  Slot s < 3 gives lane l the pair-row l + 54 s (lane 54 of slot 2: pair-row 162): its
+  // P window is symbol r of the + try, its M window symbol 162 - r of the - try -- 22 instructions per sample for the
+  // two where the split above spends 28 on two (row, hypothesis) pairs.  Slot 3 only loads.
+  auto walk_pair = [&](auto slot_tag) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const int tone = wv & 3;
+    const bool act = SLOT < 3 && (lane < K6_TROWS || (SLOT == 2 && lane == K6_TROWS));
+    const int rp = act ? lane + K6_TROWS * SLOT : 1;                       // idle lanes shadow pair-row 1
+    const int prow = min(rp, UWSPR_NSYM - 1), mrow = min(UWSPR_NSYM - rp, UWSPR_NSYM - 1);
+    const bool pok = act && rp < UWSPR_NSYM, mok = act && rp >= 1;
+    float cd, sd;
+    {
+      const float delta = ((float)tone - 1.5f) * 1.46484375f;              // cc:148
+      const float fp = (float)((double)fc + ((double)drp / 2.0) * ((double)(float)rp - 81.0) / 81.0);   // cc:173
+      double sn, cs;
+      sincos(kTwoPiDt6 * (double)(fp + delta), &sn, &cs);                  // cc:188-189
+      cd = (float)cs; sd = (float)sn;
+    }
+    float pc = 1.0f, psn = 0.0f, inpP = 0.0f, quadP = 0.0f, inpM = 0.0f, quadM = 0.0f;
+    for (int c = 0; c < nchunks; c++) {
+      gload(min(c + 1, nchunks - 1));           // in flight during the arithmetic
+      if (SLOT < 3) {
+        const lds_f *bp = &stage[(c & 1) * K6_MAXROWS * K6_ROWDW];
+        for (int half = 0; half < 2; half++) {
+          v4f xp[4], xm[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            xp[j] = *(const lds_f4 *)(bp + prow * K6_ROWDW + 16 * half + 4 * j);
+            xm[j] = *(const lds_f4 *)(bp + mrow * K6_ROWDW + 16 * half + 4 * j);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+              const float px = e ? xp[j].z : xp[j].x, py = e ? xp[j].w : xp[j].y;
+              const float mx = e ? xm[j].z : xm[j].x, my = e ? xm[j].w : xm[j].y;
+              inpP = (inpP + px * pc) + py * psn;             // cc:206
+              quadP = (quadP - px * psn) + py * pc;           // cc:207
+              inpM = (inpM + mx * pc) + my * psn;
+              quadM = (quadM - mx * psn) + my * pc;
+              const float nc = pc * cd - psn * sd;            // cc:193-195
+              const float ns = pc * sd + psn * cd;
+              pc = nc; psn = ns;
+            }
+          }
+        }
+      }
+      gstore((c + 1) & 1);
+      __syncthreads();
+    }
+    // tone magnitudes (cc:211) into the p image, which overlays the (now dead) staging buffers
+    if (pok) stage[0 * K6_PSLAB + prow * 4 + tone] = ieee_sqrtf(inpP * inpP + quadP * quadP);
+    if (mok) stage[1 * K6_PSLAB + mrow * 4 + tone] = ieee_sqrtf(inpM * inpM + quadM * quadM);
+  };
+
   gload(0);
   gstore(0);
   __syncthreads();
   // every slot executes the same number of barriers (one per chunk)
-  switch (wv >> 2) {
-    case 0: walk(std::integral_constant<int, 0>{}); break;
-    case 1: walk(std::integral_constant<int, 1>{}); break;
-    case 2: walk(std::integral_constant<int, 2>{}); break;
-    default: walk(std::integral_constant<int, 3>{}); break;
+  bool paired = false;
+  if (KIND == K6_S2) paired = uni((m_type == UWSPR_LINEAR && drp == -drm && mask == 0x3u) ? 1 : 0) != 0;
+  if (KIND == K6_S2 && paired) {
+    switch (wv >> 2) {
+      case 0: walk_pair(std::integral_constant<int, 0>{}); break;
+      case 1: walk_pair(std::integral_constant<int, 1>{}); break;
+      case 2: walk_pair(std::integral_constant<int, 2>{}); break;
+      default: walk_pair(std::integral_constant<int, 3>{}); break;
+    }
+  } else {
+    switch (wv >> 2) {
+      case 0: walk(std::integral_constant<int, 0>{}); break;
+      case 1: walk(std::integral_constant<int, 1>{}); break;
+      case 2: walk(std::integral_constant<int, 2>{}); break;
+      default: walk(std::integral_constant<int, 3>{}); break;
+    }
   }
   __syncthreads();
 }
