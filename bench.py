@@ -409,12 +409,13 @@ def main():
     fast_leg = None
     c3_leg = None
     if world == 1 and not strong and not args.no_lazy:
-        fl_lanes = make_lanes(3, False, {"fast_search": 1})
+        nfl = min(3, max_lanes)                 # --streams 1 / 2 leaves fewer lane streams than the default three
+        fl_lanes = make_lanes(nfl, False, {"fast_search": 1})
         region(fl_lanes, min(K, 10), gather=False)
         fr = sorted(region(fl_lanes, K)[0] for _ in range(3))
         close_lanes(fl_lanes)
         fast_leg = {"frames_per_s": B * K / fr[1], "ms_per_step": 1e3 * fr[1] / K, "min": B * K / fr[2], "max": B * K / fr[0],
-                    "repeats": 3, "sched": "staged", "streams": 3,
+                    "repeats": 3, "sched": "staged", "streams": nfl,
                     "what": "the timed region of `value` with uwspr_set_option(fast_search, 1): stages S0..S4 with fused "
                             "multiply-adds and wavefront shuffle-tree sums (sync metrics agree with the exact path to "
                             "~1e-6, integer results and soft symbols identical: tests/test_gpu_fast_search.py); NOT the "

@@ -78,7 +78,7 @@ struct uwspr_pipe {
   // by both without the lock.  Argument errors are not sticky: the call that made them returns UWSPR_ERR_ARG (with
   // its message), nothing in flight is harmed and the pipe goes on.
   std::atomic<int> failed{0};
-  int64_t inject_seq = -1; int inject_where = 0;   // uwspr_pipe_inject_failure (tests)
+  std::atomic<int64_t> inject_seq{-1}; std::atomic<int> inject_where{0};   // uwspr_pipe_inject_failure (tests): read by the coordinators and the producer without q->m
 
   std::vector<pipe_lane> lanes;
   double spare_after = 2.5e-3;   // seconds of host tail after which a spare lane may open (take_lane)
@@ -145,7 +145,7 @@ static int finish_batch(uwspr_pipe *q, pipe_lane &L) {
   L.recs.clear();   // (a failure below emits nothing for this batch)
   double t0 = now_s();
   PHIP(q, hipEventSynchronize(L.ev_done));
-  if (q->inject_where == 1 && L.seq == q->inject_seq) return pfail(q, UWSPR_ERR_HIP, "injected failure in the host tail of batch %lld", (long long)L.seq);
+  if (q->inject_where.load() == 1 && L.seq == q->inject_seq.load()) return pfail(q, UWSPR_ERR_HIP, "injected failure in the host tail of batch %lld", (long long)L.seq);
   double t1 = now_s();
   {
     std::lock_guard<std::mutex> lk(q->m);
@@ -327,7 +327,7 @@ static int launch(uwspr_pipe *q, pipe_lane &L, const float *frames, int B, int s
   const int per = q->per;
   L.B = B; L.stride = stride; L.frames = frames; L.pos0 = pos0; L.frame0 = q->next_frame;
   q->next_frame += B;
-  if (q->inject_where == 0 && q->next_seq == q->inject_seq)
+  if (q->inject_where.load() == 0 && q->next_seq == q->inject_seq.load())
     return pfail(q, UWSPR_ERR_HIP, "injected failure at the launch of batch %lld", (long long)q->next_seq);
   int rc = uwspr_set_frame_stride(L.ctx, stride);
   if (!rc) rc = uwspr_set_tries(L.ctx, q->o.eager ? UWSPR_NJIG : 1);
@@ -478,8 +478,7 @@ static int open_ingest(uwspr_pipe *q) {
 
 extern "C" int uwspr_pipe_inject_failure(uwspr_pipe *q, long long batch, int where) {
   if (!q || where < 0 || where > 1) return UWSPR_ERR_ARG;
-  std::lock_guard<std::mutex> lk(q->m);
-  q->inject_seq = batch; q->inject_where = where;
+  q->inject_where.store(where); q->inject_seq.store(batch);
   return UWSPR_OK;
 }
 
@@ -557,14 +556,18 @@ extern "C" int uwspr_pipe_set_option(uwspr_pipe *q, const char *name, int value)
   if (!q || !name) return UWSPR_ERR_ARG;
   if (const int f = q->failed.load()) return f;
   if (!strcmp(name, "sched")) return parg(q, "uwspr_pipe_set_option: \"sched\" belongs to uwspr_pipe_opts.sched_form");
-  {
-    std::lock_guard<std::mutex> lk(q->m);
-    for (auto &L : q->lanes)
-      if (L.busy) { snprintf(q->err, sizeof(q->err), "uwspr_pipe_set_option(%s): batches in flight (flush first)", name); return UWSPR_ERR_ARG; }
-  }
+  // checked AND applied under q->m: a lane is marked busy under the same lock when a batch is launched on it, so no
+  // batch starts between the check and the last lane's option (the producer is single-threaded by contract, the
+  // coordinators are not)
+  std::lock_guard<std::mutex> lk(q->m);
+  for (auto &L : q->lanes)
+    if (L.busy) { snprintf(q->err, sizeof(q->err), "uwspr_pipe_set_option(%s): batches in flight (flush first)", name); return UWSPR_ERR_ARG; }
   for (auto &L : q->lanes) {
     const int rc = uwspr_set_option(L.ctx, name, value);
-    if (rc) return parg(q, "uwspr_pipe_set_option(%s, %d): %s", name, value, uwspr_last_error(L.ctx));
+    if (rc) {
+      if (!q->failed.load()) snprintf(q->err, sizeof(q->err), "uwspr_pipe_set_option(%s, %d): %s", name, value, uwspr_last_error(L.ctx));
+      return UWSPR_ERR_ARG;
+    }
   }
   return UWSPR_OK;
 }

@@ -2,6 +2,7 @@
 // constructors of FDR_impl / sync_and_demodulate_impl), constant tables, HBM
 // scratch management and the launch sequences.  There is no CPU fallback: with
 // no usable HIP device every entry point fails with UWSPR_ERR_NODEVICE.
+#include <errno.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -87,30 +88,31 @@ static float slm_frequency_drift(double V1, double V2, int p1, int p2, float cf,
 // Every switch of the implementation is an option of the context: set by uwspr_set_option, or -- for experiments and
 // for the ones that shape the context when it is created (the "k1_" / "k3_" ones) -- listed in the one environment
 // variable UWSPR_OPTIONS="name=value,name=value".  Nothing else in the library reads the environment.
-static const struct { const char *name; int dflt; } kOptions[UWSPR_NOPT] = {
-    {"sched", 1},            // 1: fused kernel k6_sched; 0: staged launches
-    {"stage_kernels", 1},    // staged form: 0 flat kernel everywhere (the reference form), 1 packed / ring kernels, 2 rows form
-    {"reuse", 1},            // the hypothesis that repeats the previous stage's winner is not correlated again
-    {"phasor_tables", 1},    // lag stages read their phasors from per-slot tables
-    {"fast_search", 0},      // stages S0..S4 with fused multiply-adds and shuffle-tree sums (NOT the reference's arithmetic)
-    {"rows_mask", 31},       // stage_kernels = 2: bit per stage kind S0,S1,S3,S4,S5 that takes the rows form
-    {"k4_t", 0},             // flat kernel: tones per lane (0: by size)
-    {"k5_lanes", -1},        // fold: -1 by size, 0 wave form, 1 lanes form
-    {"k1_rows", 0},          // spectrogram: rows per wavefront walk (0: default)
-    {"k3_tile", -1},         // coarse search: tile form (-1: by size)
-    {"k3_pitch", 0},         // coarse search: tile row pitch (0: default)
-    {"sched_stamps", 0},     // diagnostics: phase times of the fused kernel (uwspr_debug_sched_stamps)
-    {"sched_grid", 0},       // fused kernel: workgroups (0: one per CU)
-    {"dist_force_comm", 0},  // tests: a one-rank communicator is really created
+static const struct { const char *name; int dflt, lo, hi; } kOptions[UWSPR_NOPT] = {
+    {"sched", 1, 0, 1},             // 1: fused kernel k6_sched; 0: staged launches
+    {"stage_kernels", 1, 0, 2},     // staged form: 0 flat kernel everywhere (the reference form), 1 packed / ring kernels, 2 rows form
+    {"reuse", 1, 0, 1},             // the hypothesis that repeats the previous stage's winner is not correlated again
+    {"phasor_tables", 1, 0, 1},     // lag stages read their phasors from per-slot tables
+    {"fast_search", 0, 0, 1},       // stages S0..S4 with fused multiply-adds and shuffle-tree sums (NOT the reference's arithmetic)
+    {"rows_mask", 31, 0, 31},       // stage_kernels = 2: bit per stage kind S0,S1,S3,S4,S5 that takes the rows form
+    {"k4_t", 0, 0, 4},              // flat kernel: tones per lane (0: by size)
+    {"k5_lanes", -1, -1, 1},        // fold: -1 by size, 0 wave form, 1 lanes form
+    {"k1_rows", 0, 0, 348},         // spectrogram: rows per wavefront walk (0: default)
+    {"k3_tile", -1, -1, 2},         // coarse search: tile form (-1: by size)
+    {"k3_pitch", 0, 0, 4096},       // coarse search: tile row pitch (0: default)
+    {"sched_stamps", 0, 0, 1},      // diagnostics: phase times of the fused kernel (uwspr_debug_sched_stamps)
+    {"sched_grid", 0, 0, 65536},    // fused kernel: workgroups (0: one per CU)
+    {"dist_force_comm", 0, 0, 1},   // tests: a one-rank communicator is really created
 };
 
 static void refresh_options(uwspr_ctx *c) {
-  c->use_fused = c->opt[UWSPR_OPT_SCHED] != 0;
   c->use_stage_kernels = c->opt[UWSPR_OPT_STAGE_KERNELS] != 0;
   c->reuse_centre = c->opt[UWSPR_OPT_REUSE] != 0;
   c->use_ptab = c->opt[UWSPR_OPT_PHASOR_TABLES] != 0;
   c->fast_search = c->opt[UWSPR_OPT_FAST_SEARCH] != 0;
-  if (c->fast_search) { c->use_fused = false; c->opt[UWSPR_OPT_SCHED] = 0; }   // the fast variant exists for the staged launches only
+  // the fast variant exists for the staged launches only: derived here, opt[] stays as the caller set it, so
+  // fast_search = 0 later brings the fused kernel back and get_option("sched") reports what was asked for
+  c->use_fused = c->opt[UWSPR_OPT_SCHED] != 0 && !c->fast_search;
   c->sched_grid = c->opt[UWSPR_OPT_SCHED_GRID];
 }
 
@@ -127,6 +129,8 @@ extern "C" int uwspr_set_option(uwspr_ctx *c, const char *name, int value) {
   if (i < 0) return fail(c, UWSPR_ERR_ARG, "unknown option '%s'", name ? name : "(null)");
   if (i == UWSPR_OPT_K1_ROWS || i == UWSPR_OPT_K3_TILE || i == UWSPR_OPT_K3_PITCH)
     return fail(c, UWSPR_ERR_ARG, "option '%s' shapes the context when it is created: UWSPR_OPTIONS=%s=%d", name, name, value);
+  if (value < kOptions[i].lo || value > kOptions[i].hi)
+    return fail(c, UWSPR_ERR_ARG, "option '%s' = %d: allowed %d .. %d", name, value, kOptions[i].lo, kOptions[i].hi);
   c->opt[i] = value; c->opt_set[i] = true;
   refresh_options(c);
   return UWSPR_OK;
@@ -145,15 +149,33 @@ static int options_from_environment(uwspr_ctx *c) {
   for (int i = 0; i < UWSPR_NOPT; i++) { c->opt[i] = kOptions[i].dflt; c->opt_set[i] = false; }
   const char *e = getenv("UWSPR_OPTIONS");
   if (e) {
+    // hand-rolled split (no strtok: contexts are created concurrently, one block per thread); every value goes through
+    // strtol with an end check and the option's range, an over-long string is an error, not a truncation
     char buf[512];
-    strncpy(buf, e, sizeof(buf) - 1); buf[sizeof(buf) - 1] = 0;
-    for (char *tok = strtok(buf, ", "); tok; tok = strtok(nullptr, ", ")) {
+    const size_t len = strlen(e);
+    if (len >= sizeof(buf)) return fail(c, UWSPR_ERR_ARG, "UWSPR_OPTIONS: %zu characters (at most %zu)", len, sizeof(buf) - 1);
+    memcpy(buf, e, len + 1);
+    char *tok = buf;
+    while (*tok) {
+      while (*tok == ',' || *tok == ' ') tok++;
+      if (!*tok) break;
+      char *end = tok;
+      while (*end && *end != ',' && *end != ' ') end++;
+      const bool last = *end == 0;
+      *end = 0;
       char *eq = strchr(tok, '=');
       if (!eq) return fail(c, UWSPR_ERR_ARG, "UWSPR_OPTIONS: '%s' is not name=value", tok);
       *eq = 0;
       const int i = option_index(tok);
       if (i < 0) return fail(c, UWSPR_ERR_ARG, "UWSPR_OPTIONS: unknown option '%s'", tok);
-      c->opt[i] = atoi(eq + 1); c->opt_set[i] = true;
+      char *vend = nullptr;
+      errno = 0;
+      const long v = strtol(eq + 1, &vend, 10);
+      if (vend == eq + 1 || *vend || errno || v < kOptions[i].lo || v > kOptions[i].hi)
+        return fail(c, UWSPR_ERR_ARG, "UWSPR_OPTIONS: %s='%s' is not an integer in %d .. %d", tok, eq + 1, kOptions[i].lo, kOptions[i].hi);
+      c->opt[i] = (int)v; c->opt_set[i] = true;
+      if (last) break;
+      tok = end + 1;
     }
   }
   refresh_options(c);

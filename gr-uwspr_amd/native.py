@@ -48,6 +48,22 @@ def _hipcc():
     raise UwsprError(-4, "hipcc not found")
 
 
+def _compiler_id():
+    """What identifies the compiler in the build stamp without starting it on every import: the resolved
+    path of hipcc, its size and the ROCm release file next to it (another ROCm => another stamp => rebuild).
+    "absent" when there is no compiler: a shipped library whose stamp says otherwise is then still used."""
+    try:
+        cc = os.path.realpath(_hipcc())
+    except UwsprError:
+        return "hipcc absent"
+    ver = ""
+    for v in (os.path.join(os.path.dirname(os.path.dirname(cc)), ".info", "version"), "/opt/rocm/.info/version"):
+        if os.path.exists(v):
+            ver = open(v).read().strip()
+            break
+    return "%s size %d rocm %s" % (cc, os.path.getsize(cc), ver)
+
+
 def _digest(paths):
     """Content hash of the build inputs: what decides whether the library is current (file
     times do not survive a copy to another machine; contents do)."""
@@ -78,7 +94,8 @@ def build(force=False, verbose=False):
     what decides "current" is the flags + the CONTENTS of the sources (a stamp next to the library) -- not file
     times and not the directory the tree happens to live in, neither of which survives the copy to a GPU box."""
     import fcntl
-    os.makedirs(LIBDIR, exist_ok=True)
+    if not os.path.isdir(LIBDIR):
+        os.makedirs(LIBDIR, exist_ok=True)
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     deps.append(os.path.join(_HERE, "..", "include", "uwspr_hip.h"))
@@ -111,18 +128,39 @@ def build(force=False, verbose=False):
             f.write(want)
         os.replace(tmp, out + ".cmd")
 
-    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+    cid = _compiler_id()
+    want = " ".join(flags + [os.path.basename(q) for q in srcs]) + "\n" + _digest(deps) + "\n" + cid
+    hwant = " ".join(hflags + [os.path.basename(q) for q in hsrcs]) + "\n" + _digest(hdeps + deps) + "\n" + cid
+
+    def all_current():
+        return current(LIBPATH, want) and (not hsrcs or bool(extra) or current(HOSTLIB, hwant))
+
+    # the common case -- a shipped, current library -- takes no lock and writes nothing (a read-only tree imports)
+    if not force and all_current():
+        return LIBPATH
+    if cid == "hipcc absent" and not force and os.path.exists(LIBPATH):
+        return LIBPATH                       # nothing to rebuild with: the loader decides whether the file is usable
+    lock = None
+    try:
+        lock = open(os.path.join(LIBDIR, ".build.lock"), "w")
         fcntl.flock(lock, fcntl.LOCK_EX)     # (released when the file is closed)
-        want = " ".join(flags + [os.path.basename(q) for q in srcs]) + "\n" + _digest(deps)
+    except OSError as e:                     # EROFS / EACCES: build (if it must) without the lock
+        import errno
+        if e.errno not in (errno.EROFS, errno.EACCES, errno.EPERM):
+            raise
+        lock = None
+    try:
         if force or not current(LIBPATH, want):
             atomically([_hipcc()] + flags + srcs + ["-ldl"], LIBPATH)
             stamp(LIBPATH, want)
         if hsrcs and not extra:
-            hwant = " ".join(hflags + [os.path.basename(q) for q in hsrcs]) + "\n" + _digest(hdeps + deps)
             if force or not current(HOSTLIB, hwant):
                 atomically(["g++"] + hflags + ["-I" + hostdir, "-I" + os.path.join(_HERE, "..", "include")] + hsrcs +
                            ["-L" + LIBDIR, "-luwspr_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"], HOSTLIB)
                 stamp(HOSTLIB, hwant)
+    finally:
+        if lock is not None:
+            lock.close()
     return LIBPATH
 
 
