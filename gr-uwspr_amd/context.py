@@ -499,12 +499,21 @@ def unpack_message(message7):
     return rc, buf.value.decode("ascii", "replace")
 
 
-def frontend_taps():
-    """Complex taps g[k] = h[k]*exp(-j*pi*(D-k)/4) of the K0 front-end (float32)."""
-    n = N.lib().uwspr_frontend_taps(None, 0)
-    g = np.zeros((n, 2), np.float32)
-    N.lib().uwspr_frontend_taps(C.c_void_p(g.ctypes.data), n)
-    return g[:, 0] + 1j * g[:, 1]
+FRONTEND_GRC, FRONTEND_COMPACT = 0, 1
+
+
+def frontend_design(mode=FRONTEND_GRC, stage=0):
+    """uwspr_frontend_design: stage 0 -> (complex128 composite taps g, read-ahead D) of the K0 front-end
+    y[m] = sum_k g[k] x[32 m + D - k]; stages 1..3 (grc mode) -> the band-pass, low-pass and resampler designs."""
+    d = C.c_int32(0)
+    n = N.lib().uwspr_frontend_design(mode, stage, None, 0, C.byref(d))
+    if n < 0:
+        raise N.UwsprError(n, "uwspr_frontend_design(mode=%d, stage=%d)" % (mode, stage))
+    g = np.zeros(n * (2 if stage == 0 else 1), np.float64)
+    N.lib().uwspr_frontend_design(mode, stage, C.c_void_p(g.ctypes.data), n, C.byref(d))
+    if stage == 0:
+        return g[0::2] + 1j * g[1::2], int(d.value)
+    return g
 
 
 def c2_read(path):

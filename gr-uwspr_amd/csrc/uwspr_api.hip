@@ -103,6 +103,7 @@ static const struct { const char *name; int dflt, lo, hi; } kOptions[UWSPR_NOPT]
     {"sched_stamps", 0, 0, 1},      // diagnostics: phase times of the fused kernel (uwspr_debug_sched_stamps)
     {"sched_grid", 0, 0, 65536},    // fused kernel: workgroups (0: one per CU)
     {"dist_force_comm", 0, 0, 1},   // tests: a one-rank communicator is really created
+    {"frontend", 0, 0, 1},          // K0: 0 the flowgraph's GNU Radio chain as one polyphase FIR (grc:303-400,840-956,1767-1808), 1 compact single stage
 };
 
 static void refresh_options(uwspr_ctx *c) {
@@ -193,7 +194,7 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->device = device;
   c->own_stream = c->stream = nullptr;
   c->d_window = c->d_twiddle = nullptr; c->d_off = nullptr; c->d_umap = nullptr; c->d_k3_tile = nullptr;
-  c->d_fe_taps = nullptr; c->cap_audio = 0; c->d_audio = nullptr;
+  c->d_fe_taps = nullptr; c->fe_mode = -1; c->fe_J = 0; c->fe_dcols = 0; c->cap_audio = 0; c->d_audio = nullptr;
   c->cap_frames_bytes = 0; c->d_frames = nullptr; c->cap_B = 0;
   c->d_ps = c->d_psavg = c->d_smraw = c->d_smspec = c->d_noise = nullptr;
   c->d_cands = nullptr; c->d_npk = nullptr; c->d_work = nullptr; c->last_B = 0; c->num_cus = 256;
@@ -511,11 +512,16 @@ extern "C" int uwspr_frontend_batch(uwspr_ctx *c, const float *audio, int B, int
   const int nout = c->fc.fl;
   if (!audio || !frames_out || B <= 0 || nin <= 0) return fail(c, UWSPR_ERR_ARG, "uwspr_frontend_batch: audio/out/B/nin");
   if (c->p.fs != 375) return fail(c, UWSPR_ERR_UNSUPPORTED, "front-end is 12000 -> 375 S/s (fs=%d)", c->p.fs);
-  if (!c->d_fe_taps) {
-    std::vector<float> g;
-    frontend_taps(g);
-    HIPCHK(c, hipMalloc((void **)&c->d_fe_taps, g.size() * sizeof(float)));
-    HIPCHK(c, hipMemcpy(c->d_fe_taps, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (!c->d_fe_taps || c->fe_mode != c->opt[UWSPR_OPT_FRONTEND]) {
+    std::vector<float> img;
+    int J = 0, dcols = 0;
+    if (frontend_tap_image(c->opt[UWSPR_OPT_FRONTEND], img, &J, &dcols)) return fail(c, UWSPR_ERR_ARG, "front-end mode %d", c->opt[UWSPR_OPT_FRONTEND]);
+    if (frontend_prepare()) return fail(c, UWSPR_ERR_HIP, "front-end kernel: %zu bytes of LDS refused", (size_t)160 * 1024);
+    HIPCHK(c, hipStreamSynchronize(c->stream));          // (a launch with the other mode's taps may be in flight)
+    if (c->d_fe_taps) { HIPCHK(c, hipFree(c->d_fe_taps)); c->d_fe_taps = nullptr; }
+    HIPCHK(c, hipMalloc((void **)&c->d_fe_taps, img.size() * sizeof(float)));
+    HIPCHK(c, hipMemcpy(c->d_fe_taps, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->fe_mode = c->opt[UWSPR_OPT_FRONTEND]; c->fe_J = J; c->fe_dcols = dcols;
   }
   const float *da = audio;
   float *dout = frames_out;
@@ -539,11 +545,17 @@ extern "C" int uwspr_frontend_batch(uwspr_ctx *c, const float *audio, int B, int
   return UWSPR_OK;
 }
 
-extern "C" int uwspr_frontend_taps(float *taps_re_im, int cap_pairs) {
-  std::vector<float> g;
-  frontend_taps(g);
-  const int n = (int)g.size() / 2;
-  if (taps_re_im) for (int i = 0; i < 2 * std::min(n, cap_pairs); i++) taps_re_im[i] = g[i];
+extern "C" int uwspr_frontend_design(int mode, int stage, double *taps, int cap, int *delay) {
+  std::vector<double> g;
+  int d = 0;
+  const int rc = frontend_design(mode, stage, g, &d);
+  if (rc) return rc;
+  if (delay) *delay = d;
+  const int n = stage == 0 ? (int)g.size() / 2 : (int)g.size();     // complex pairs / real taps
+  if (taps) {
+    const int k = (stage == 0 ? 2 : 1) * std::min(n, cap < 0 ? 0 : cap);
+    for (int i = 0; i < k; i++) taps[i] = g[i];
+  }
   return n;
 }
 

@@ -26,6 +26,7 @@ enum {
   UWSPR_OPT_SCHED_STAMPS,       // diagnostics: phase times of the fused kernel
   UWSPR_OPT_SCHED_GRID,         // fused kernel: workgroups (0 = one per CU)
   UWSPR_OPT_DIST_FORCE_COMM,    // tests: a one-rank communicator is really created
+  UWSPR_OPT_FRONTEND,           // K0 taps: 0 the flowgraph's three-stage GNU Radio chain (default), 1 the compact single stage
   UWSPR_NOPT
 };
 
@@ -163,7 +164,8 @@ struct uwspr_ctx {
   float *d_k3_tile;    // [num_cus][n][tp] sqrt rows when the coarse tile does not fit LDS (K3_TILE_F1_HBM), else null
   uint32_t *d_off;     // [n_ifr][umax][84]: distinct offset sequences, 2 x u16 tile byte offsets per word (k3_coarse.hip)
   uint16_t *d_umap;    // [n_ifr][cell_hyps]: hypothesis -> distinct sequence
-  float *d_fe_taps;    // [1025][2] complex front-end taps (K0), built on first use
+  float *d_fe_taps;    // [32][fe_J][2] complex front-end taps by phase (K0), built on first use for mode fe_mode
+  int fe_mode, fe_J, fe_dcols;
   size_t cap_audio; float *d_audio;   // staging when the audio is host memory
 
   // batch scratch (grown on demand, never shrunk)
@@ -240,7 +242,9 @@ struct uwspr_ctx {
 namespace uwspr {
 
 // ---- launchers (each enqueues on ctx->stream) ------------------------------
-void frontend_taps(std::vector<float> &g);
+int frontend_design(int mode, int stage, std::vector<double> &out, int *delay);
+int frontend_tap_image(int mode, std::vector<float> &img, int *J, int *dcols);
+int frontend_prepare();
 void launch_frontend(uwspr_ctx *c, const float *audio, int B, int nin, float2 *out, int nout);
 void launch_spectrogram(uwspr_ctx *c, const float *frames, int B);
 void launch_spectrum(uwspr_ctx *c, int B);

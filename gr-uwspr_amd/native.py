@@ -229,7 +229,7 @@ class Prof(C.Structure):
 ABI_SYMBOLS = [
     "uwspr_ctx_create", "uwspr_ctx_destroy", "uwspr_last_error", "uwspr_status_string",
     "uwspr_get_info", "uwspr_set_stream", "uwspr_synchronize", "uwspr_frontend_batch",
-    "uwspr_frontend_taps", "uwspr_set_frame_stride", "uwspr_stream_open", "uwspr_stream_push", "uwspr_stream_wait_uploads",
+    "uwspr_frontend_design", "uwspr_set_frame_stride", "uwspr_stream_open", "uwspr_stream_push", "uwspr_stream_wait_uploads",
     "uwspr_stream_take_view", "uwspr_stream_take", "uwspr_stream_reset",
     "uwspr_device_alloc", "uwspr_device_free", "uwspr_host_alloc", "uwspr_host_free", "uwspr_fdr_batch",
     "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
@@ -280,7 +280,7 @@ def lib():
     L.uwspr_set_stream.argtypes = [vp, vp]
     L.uwspr_synchronize.argtypes = [vp]
     L.uwspr_frontend_batch.argtypes = [vp, vp, ip, ip, ip, vp]
-    L.uwspr_frontend_taps.argtypes = [vp, ip]
+    L.uwspr_frontend_design.argtypes = [ip, ip, vp, ip, vp]
     L.uwspr_stream_open.argtypes = [vp, ip, ip]
     L.uwspr_stream_push.argtypes = [vp, vp, ip, ip, C.POINTER(C.c_int)]
     L.uwspr_stream_take.argtypes = [vp, ip, vp, C.POINTER(vp), C.POINTER(C.c_longlong)]

@@ -28,9 +28,11 @@
 extern "C" {
 #endif
 
-#define UWSPR_ABI_VERSION 3   /* 2: frame stride, in-place stream views, uwspr_pipe_*, uwspr_dist_*, uwspr_host_threads;
+#define UWSPR_ABI_VERSION 4   /* 2: frame stride, in-place stream views, uwspr_pipe_*, uwspr_dist_*, uwspr_host_threads;
                                  3: uwspr_set_option / uwspr_get_option, uwspr_pipe_set_option, uwspr_pipe_inject_failure,
-                                    uwspr_pipe_opts.spare_after_us (was reserved) */
+                                    uwspr_pipe_opts.spare_after_us (was reserved);
+                                 4: option "frontend" (the flowgraph's GNU Radio chain is the default front-end),
+                                    uwspr_frontend_design replaces uwspr_frontend_taps */
 
 typedef enum {
   UWSPR_OK = 0,
@@ -148,16 +150,25 @@ int uwspr_set_stream(uwspr_ctx *ctx, void *hip_stream);
 int uwspr_synchronize(uwspr_ctx *ctx);
 
 /* ---- front-end -------------------------------------- */
-/* 12 kS/s real audio -> fl complex samples at 375 S/s: mix by -1500 Hz, 1025-tap
- * Hamming low-pass (100 Hz), decimate by 32 -- our own single-stage equivalent of
- * the GNU Radio filter chain of examples/WaveFilePlusNoiseDecode.grc:840-916,
- * 1767-1768 (third-party blocks; taps are version-dependent: parity unpinned).
- * audio [B][nin] (zero beyond the record), frames_out [B][fl] (I,Q) pairs.
- * uwspr_frontend_taps returns the tap count and copies the complex taps
- * h[k]*exp(-j*pi*(D-k)/4) so a caller can restate the formula. */
+/* 12 kS/s real audio -> fl complex samples at 375 S/s.  In the reference this is the flowgraph's chain of GNU Radio
+ * blocks (examples/WaveFilePlusNoiseDecode.grc): float_to_complex (:527) -> freq_xlating_fft_filter_ccc with
+ * firdes.band_pass(1, 12000, 1490, 1510, 10, WIN_HAMMING) real taps at centre 0 (:303-352, 840-893) ->
+ * freq_xlating_fft_filter_ccc with firdes.low_pass(1, 12000, 1510, 10, WIN_HAMMING) at centre 1500 Hz (:358-400,
+ * 903-956) -> rational_resampler_ccc(1, 32) with its own Kaiser design (:1767-1808).
+ *   option "frontend" = 0 (UWSPR_FRONTEND_GRC, default): that chain, its taps designed from GNU Radio 3.7's published
+ *     formulas and folded into ONE 6831-tap complex polyphase decimator (every stage is linear, the mixer's period
+ *     divides the decimation): y[m] = sum_k g[k] x[32 m - k];
+ *   option "frontend" = 1 (UWSPR_FRONTEND_COMPACT): mix by -1500 Hz, 1025-tap Hamming low-pass (100 Hz), decimate:
+ *     y[m] = sum_k g[k] x[32 m + 512 - k] -- a sixth of the arithmetic, not the reference's pass band.
+ * GNU Radio is third-party, unpinned and absent here: **parity unpinned**; oracle/frontend_grc.py restates the chain
+ * stage by stage in binary64.  audio [B][nin] (zero outside the record), frames_out [B][fl] (I,Q) pairs.
+ * uwspr_frontend_design: stage 0 = the composite complex taps g (cap counts (re, im) pairs) and *delay = D of
+ * y[m] = sum_k g[k] x[32 m + D - k]; stages 1, 2, 3 (grc mode) = the band-pass, low-pass and resampler designs
+ * (real taps).  Returns the tap count (taps may be NULL), < 0 on a bad mode / stage. */
+enum { UWSPR_FRONTEND_GRC = 0, UWSPR_FRONTEND_COMPACT = 1 };
 int uwspr_frontend_batch(uwspr_ctx *ctx, const float *audio, int B, int nin, int where,
                          float *frames_out);
-int uwspr_frontend_taps(float *taps_re_im, int cap_pairs);
+int uwspr_frontend_design(int mode, int stage, double *taps, int cap, int *delay);
 
 /* ---- overlap-aware stream ingest ----------------------- */
 /* sliding_window_stream_to_pdu::work (lib/sliding_window_stream_to_pdu_impl.cc:97-138) cuts the

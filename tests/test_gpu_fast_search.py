@@ -24,7 +24,22 @@ CHUNK, PER = 300, 2
 def test_fast_search_agrees_with_the_exact_schedule(G):
     cx = G.Context(options={"sched": 0})
     cf = G.Context(options={"fast_search": 1})
-    assert cf.get_option("sched") == 0                      # the fast variant exists for the staged launches only
+    # the fast variant exists for the staged launches only: the context runs them while the option is set (the caller's
+    # "sched" stays what it was) and goes back to the fused kernel when it is cleared
+    assert cf.get_option("sched") == 1
+    probe = G.synth.make_frames(4, seed=1, snr_db=-20.0, maxdrift=0.0)
+
+    def k4_launches(ctx):
+        ctx.prof_enable(True)
+        ctx.prof_read()
+        ctx.pipeline_batch(probe, max_per_frame=1)
+        n = ctx.prof_read()["tonecorr"]["launches"]
+        ctx.prof_enable(False)
+        return n
+    assert k4_launches(cf) >= 5
+    cf.set_option("fast_search", 0)
+    assert k4_launches(cf) == 1 and cf.get_option("sched") == 1
+    cf.set_option("fast_search", 1)
     ncand = nworth = 0
     worst = 0.0
     try:
