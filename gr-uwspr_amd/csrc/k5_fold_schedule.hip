@@ -604,8 +604,6 @@ __device__ __forceinline__ float fold_wave_fast(const dev_hyp *__restrict__ hyps
   return ieee_divf(wave_sum(sm), wave_sum(tp));
 }
 
-constexpr int K5S_PITCH = UWSPR_NSYM + 1;   // float4 per stream (+1: the serial lanes start in different banks)
-#if defined(UWSPR_FOLD_STEP_WAVES) && UWSPR_FOLD_STEP_WAVES   // (A/B builds only: rounds 2-4, one wavefront per hypothesis)
 template <int STAGE, bool FAST = false>
 __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__restrict__ hin,
                              const float4 *__restrict__ p, float *__restrict__ sync,
@@ -630,81 +628,6 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
     else s = fold_wave<false>(hin, p, h, 50.0f, nullptr, L[FAST ? 0 : q], nullptr);
     if ((threadIdx.x & 63) == 0) { sy[q] = s; sync[h] = s; }
   }
-#else
-// Round 5: ONE wavefront per slot.  The slot's NIN hypotheses are folded side by side in its lanes -- lane 2 q adds
-// hypothesis q's 648 magnitudes (cc:213), lane 2 q + 1 its 162 signed metrics (cc:215), each in the reference's order
-// -- where rounds 2-4 spent a whole wavefront per hypothesis on those two serial sums: the same longest chain (648
-// dependent additions), a fifth of the wave-instructions (the chip's VALU issue is what the three-stream step is
-// short of), 64 threads per slot instead of 320.
-template <int STAGE, bool FAST = false>
-__global__ __launch_bounds__(64) void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__restrict__ hin,
-                             const float4 *__restrict__ p, float *__restrict__ sync,
-                             dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
-                             uwspr_candidate *__restrict__ cent, int32_t *__restrict__ cframe, int nslots,
-                             int reuse, int njig, float4 *__restrict__ pwin, float2 *__restrict__ ptab,
-                             dev_row *__restrict__ rows) {
-  UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
-  constexpr int NIN = STAGE == 3 ? 2 : 5;
-  __shared__ __align__(16) float4 str[FAST ? 1 : NIN * 2 * K5S_PITCH];   // [hypothesis][magnitudes | (0,0,0,+-cmet)][symbol]
-  __shared__ float sy[NIN];
-  __shared__ int s_wsrc;
-  const int slot = blockIdx.x;
-  const int lane = threadIdx.x;
-  int fr[NIN];
-#pragma unroll
-  for (int q = 0; q < NIN; q++) fr[q] = hin[slot * NIN + q].frame;    // wavefront-uniform
-  if (FAST) {
-#pragma unroll
-    for (int q = 0; q < NIN; q++) {
-      const int h = slot * NIN + q;
-      // a hypothesis marked known (frame <= -2) repeats the previous winner: its metric is in the state
-      const float s = fr[q] <= -2 ? state[slot].csync : fold_wave_fast(hin, p, h);
-      if (lane == 0) { sy[q] = s; sync[h] = s; }
-    }
-  } else {
-    // per-symbol terms of every live hypothesis, by all lanes (coalesced loads, all issued before the first use)
-    float4 P[NIN][3];
-#pragma unroll
-    for (int q = 0; q < NIN; q++)
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const int i = lane + 64 * r;
-        if (fr[q] >= 0 && i < UWSPR_NSYM) P[q][r] = p[(size_t)(slot * NIN + q) * UWSPR_NSYM + i];
-      }
-#pragma unroll
-    for (int q = 0; q < NIN; q++)
-#pragma unroll
-      for (int r = 0; r < 3; r++) {
-        const int i = lane + 64 * r;
-        if (fr[q] >= 0 && i < UWSPR_NSYM) {
-          const float4 v = P[q][r];
-          const float cmet = (v.y + v.w) - (v.x + v.z);   // cc:214
-          str[(2 * q) * K5S_PITCH + i] = v;
-          // ss -/+ cmet == ss + (-/+cmet); the three +0 terms leave ss unchanged
-          str[(2 * q + 1) * K5S_PITCH + i] = make_float4(0.0f, 0.0f, 0.0f, pr3_rt(i) ? cmet : -cmet);
-        }
-      }
-    k5_wave_fence();
-    float acc = 0.0f;
-    bool mine = false;                                 // (a dead or known hypothesis has no stream: its lanes idle)
-#pragma unroll
-    for (int q = 0; q < NIN; q++) mine = ((lane >> 1) == q) ? fr[q] >= 0 : mine;
-    if (mine) {
-      const float4 *st = &str[lane * K5S_PITCH];
-#pragma unroll 9
-      for (int i = 0; i < UWSPR_NSYM; i++) {
-        const float4 v = st[i];
-        acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w;
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NIN; q++) {
-      const float totp = __shfl(acc, 2 * q), ss = __shfl(acc, 2 * q + 1);
-      const float s = fr[q] <= -2 ? state[slot].csync : fr[q] < 0 ? -1e30f : ieee_divf(ss, totp);   // cc:226
-      if (lane == 0) { sy[q] = s; sync[slot * NIN + q] = s; }
-    }
-  }
-#endif
   __syncthreads();
   if (STAGE == 5) {
     if (threadIdx.x < UWSPR_NJIG + 3)
@@ -738,9 +661,22 @@ __global__ void k_sched_finish(const cand_state *__restrict__ state,
   UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   const int slot = blockIdx.x;
   if (slot >= nslots) return;
+  const int tid = threadIdx.x;
+  // the slot's njig x 162 symbol bytes are requested first, whether or not the slot is on (they exist either way: masked
+  // below), so that they travel beside the state instead of behind it (round 5)
+  constexpr int K5F_HALFWORDS = (UWSPR_NJIG * UWSPR_NSYM + 2) / 2, K5F_ROUNDS = (K5F_HALFWORDS + 255) / 256;
+  uint16_t symv[K5F_ROUNDS];
+  {
+    const uint16_t *src = reinterpret_cast<const uint16_t *>(sym5 + (size_t)slot * njig * UWSPR_NSYM);   // (even offset)
+    const int have = njig * UWSPR_NSYM;
+#pragma unroll
+    for (int j = 0; j < K5F_ROUNDS; j++) {
+      const int e = tid + 256 * j;
+      symv[j] = (e < K5F_HALFWORDS && 2 * e < have) ? src[e] : (uint16_t)0;
+    }
+  }
   const cand_state st = state[slot];
   uwspr_demod_out *o = out + slot;
-  const int tid = threadIdx.x;
   if (tid == 0) {
     o->f1 = st.f1; o->drift1 = st.drift1; o->sync1 = st.sync1; o->shift1 = st.shift1;
     o->worth_a_try = st.worth;
@@ -757,9 +693,12 @@ __global__ void k_sched_finish(const cand_state *__restrict__ state,
   __shared__ __align__(4) uint8_t sy_s[UWSPR_NJIG * UWSPR_NSYM + 2];
   const int nby = on ? njig * UWSPR_NSYM : 0;
   {
-    const uint16_t *src = reinterpret_cast<const uint16_t *>(sym5 + (size_t)slot * njig * UWSPR_NSYM);   // (even offset)
     uint16_t *dst = reinterpret_cast<uint16_t *>(sy_s);
-    for (int e = tid; e < (UWSPR_NJIG * UWSPR_NSYM + 2) / 2; e += blockDim.x) dst[e] = 2 * e < nby ? src[e] : (uint16_t)0;
+#pragma unroll
+    for (int j = 0; j < K5F_ROUNDS; j++) {
+      const int e = tid + 256 * j;
+      if (e < K5F_HALFWORDS) dst[e] = 2 * e < nby ? symv[j] : (uint16_t)0;
+    }
   }
   __syncthreads();
   if (tid < UWSPR_NJIG) {
@@ -791,147 +730,6 @@ __global__ void k_sched_finish(const cand_state *__restrict__ state,
     const uint32_t *cw = reinterpret_cast<const uint32_t *>(cands + (size_t)b * maxfreqs);
     const int n = npk[b];
     for (int w = tid; w < words; w += blockDim.x) {
-      uint32_t v = 0;
-      if (w == 0) v = (uint32_t)n;
-      else if (w >= 4 && w < 4 + K * 12) { const int k = (w - 4) / 12; v = (k < n && k < maxfreqs) ? cw[w - 4] : 0u; }
-      else if (w >= 4 + K * 12) {
-        const int t = w - 4 - K * 12;
-        v = t == 0 ? __float_as_uint(st.f1) : t == 1 ? __float_as_uint(st.drift1) : t == 2 ? __float_as_uint(st.sync1) : (uint32_t)st.shift1;
-      }
-      so[w] = v;
-    }
-  }
-}
-
-// Round 5: stage 5's soft fold (cc:213-226, 240-254 for each of the slot's njig tries) and k_sched_finish (cc:465-475)
-// as ONE launch, one 4-wavefront workgroup per slot.  The tries are folded side by side: wavefront 0 adds the 648
-// magnitudes of try t in lane t (cc:213), wavefront 1 the 162 signed metrics (cc:215), wavefronts 2 / 3 the binary64-
-// stepped fsum / f2sum (cc:243-244) -- every sum in the reference's order, its terms formed by all 256 threads -- where
-// k5_fold_wave spends a wavefront per try on the same four chains (17 x the wave-instructions).  The soft symbols go
-// straight into the record's LDS image: no sync5 / sym5 round trip through HBM, one launch less on the lane's chain.
-// GT tries share the LDS streams at a time (GT = 9: 47 KB).
-template <int GT>
-__global__ __launch_bounds__(256) void k5_fold5_finish(const cand_state *__restrict__ state, const dev_hyp *__restrict__ h5,
-                                                       const float4 *__restrict__ p, const float4 *__restrict__ pwin,
-                                                       uwspr_demod_out *__restrict__ out, int nslots, int njig,
-                                                       const uwspr_candidate *__restrict__ cands,
-                                                       const int32_t *__restrict__ npk, int maxfreqs, int per_frame, int K,
-                                                       uint8_t *__restrict__ slab) {
-  UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
-  static_assert((UWSPR_NJIG * UWSPR_NSYM) % 2 == 0 && UWSPR_NSYM % 2 == 0, "two-byte accesses below");
-  static_assert(offsetof(uwspr_demod_out, symbols) % 4 == 0 && sizeof(uwspr_demod_out) % 4 == 0 &&
-                offsetof(uwspr_demod_out, _pad) == offsetof(uwspr_demod_out, symbols) + UWSPR_NJIG * UWSPR_NSYM &&
-                sizeof(((uwspr_demod_out *)0)->_pad) == 2, "symbols + pad are written as 32-bit words below");
-  __shared__ __align__(16) float4 mag[GT][K5S_PITCH];
-  __shared__ __align__(16) double q0[GT][UWSPR_NSYM], q1[GT][UWSPR_NSYM];   // fs/162, fs*fs/162
-  __shared__ float res[UWSPR_NJIG][4];                                        // totp, ss, fsum, f2sum
-  __shared__ float jsync[UWSPR_NJIG];
-  __shared__ int jlive[UWSPR_NJIG];                                           // 0 dead, 1 from p, 2 from the kept row
-  __shared__ __align__(4) uint8_t sy_s[UWSPR_NJIG * UWSPR_NSYM + 2];
-  const int slot = blockIdx.x;
-  if (slot >= nslots) return;
-  const cand_state st = state[slot];
-  uwspr_demod_out *o = out + slot;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int kind = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool on = st.frame >= 0 && st.worth;
-  if (tid == 0) {
-    o->f1 = st.f1; o->drift1 = st.drift1; o->sync1 = st.sync1; o->shift1 = st.shift1;
-    o->worth_a_try = st.worth;
-  }
-  if (tid < UWSPR_NJIG) {
-    // a try marked known (frame <= -2: try 0 repeating the stage-4 winner) is folded from the slot's kept magnitudes
-    const int fr = (on && tid < njig) ? h5[(size_t)slot * njig + tid].frame : -1;
-    jlive[tid] = fr >= 0 ? 1 : (fr <= -2 && pwin != nullptr) ? 2 : 0;
-    jsync[tid] = -1e30f;
-  }
-  for (int e = tid; e < (UWSPR_NJIG * UWSPR_NSYM + 2) / 4; e += 256) reinterpret_cast<uint32_t *>(sy_s)[e] = 0u;
-  __syncthreads();
-  const int ntry = on ? njig : 0;
-  for (int t0 = 0; t0 < ntry; t0 += GT) {
-    const int gt = min(GT, ntry - t0);
-    // ---- the per-symbol terms, by everyone
-    for (int item = tid; item < gt * UWSPR_NSYM; item += 256) {
-      const int tt = item / UWSPR_NSYM, i = item - tt * UWSPR_NSYM, t = t0 + tt;
-      const int lv = jlive[t];
-      if (!lv) continue;
-      const float4 P = lv == 2 ? pwin[(size_t)slot * UWSPR_NSYM + i] : p[((size_t)slot * njig + t) * UWSPR_NSYM + i];
-      const float fs = pr3_rt(i) ? P.w - P.y : P.z - P.x;      // cc:219,222
-      mag[tt][i] = P;
-      q0[tt][i] = (double)fs / 162.0;                          // cc:243
-      q1[tt][i] = (double)(fs * fs) / 162.0;                   // cc:244
-    }
-    __syncthreads();
-    // ---- the four order-sensitive sums: one kind per wavefront, one try per lane
-    if (lane < gt && jlive[t0 + lane]) {
-      float acc = 0.0f;
-      if (kind == 0) {
-#pragma unroll 9
-        for (int i = 0; i < UWSPR_NSYM; i++) {
-          const float4 P = mag[lane][i];
-          acc = acc + P.x; acc = acc + P.y; acc = acc + P.z; acc = acc + P.w;     // cc:213
-        }
-      } else if (kind == 1) {
-#pragma unroll 9
-        for (int i = 0; i < UWSPR_NSYM; i++) {
-          const float4 P = mag[lane][i];
-          const float cmet = (P.y + P.w) - (P.x + P.z);                          // cc:214
-          acc = pr3_rt(i) ? acc + cmet : acc - cmet;                             // cc:215
-        }
-      } else {
-        const double *q = kind == 2 ? q0[lane] : q1[lane];
-#pragma unroll 9
-        for (int i = 0; i < UWSPR_NSYM; i++) acc = (float)((double)acc + q[i]);   // cc:243-244
-      }
-      res[t0 + lane][kind] = acc;
-    }
-    __syncthreads();
-    // ---- soft symbols (cc:246-251) into the record's image
-    for (int item = tid; item < gt * UWSPR_NSYM; item += 256) {
-      const int tt = item / UWSPR_NSYM, i = item - tt * UWSPR_NSYM, t = t0 + tt;
-      if (!jlive[t]) continue;
-      const float fsum = res[t][2], f2sum = res[t][3];
-      const float fac = ieee_sqrtf(f2sum - fsum * fsum);       // cc:246
-      const float4 P = mag[tt][i];
-      const float fs = pr3_rt(i) ? P.w - P.y : P.z - P.x;
-      float v = ieee_divf(50.0f * fs, fac);                    // cc:248 (symfac = 50)
-      if (v > 127.0f) v = 127.0f;
-      if (v < -128.0f) v = -128.0f;
-      v = v + 128.0f;
-      sy_s[t * UWSPR_NSYM + i] = (v != v) ? (uint8_t)0 : (uint8_t)(int)v;   // cc:251 (NaN -> 0)
-      if (i == 0) jsync[t] = ieee_divf(res[t][1], res[t][0]);  // cc:226
-    }
-    __syncthreads();
-  }
-  // ---- the record (k_sched_finish): per-try rms over the bytes (cc:471-474), sync, shift, symbols
-  if (tid < UWSPR_NJIG) {
-    const bool have = on && tid < njig;
-    float rms = 0.0f;
-    if (have) {
-      float sq = 0.0f;
-#pragma unroll 6
-      for (int i = 0; i < UWSPR_NSYM; i++) {
-        const float y = (float)((double)(float)sy_s[tid * UWSPR_NSYM + i] - 128.0);  // cc:471
-        sq += y * y;
-      }
-      rms = (float)sqrt((double)sq / 162.0);  // cc:474
-    }
-    o->jig_sync[tid] = have ? jsync[tid] : 0.0f;
-    o->jig_rms[tid] = rms;
-    o->jig_shift[tid] = have ? h5[(size_t)slot * njig + tid].lag : 0;
-  }
-  {   // symbols + the two pad bytes (zero) as 689 words
-    uint32_t *dst = reinterpret_cast<uint32_t *>(&o->symbols[0][0]);
-    const uint32_t *src = reinterpret_cast<const uint32_t *>(sy_s);
-    for (int e = tid; e < (UWSPR_NJIG * UWSPR_NSYM + 2) / 4; e += 256) dst[e] = src[e];
-  }
-  if (slab != nullptr && slot % per_frame == 0) {
-    const int b = slot / per_frame;
-    const int slab_bytes = 16 + K * 48 + 16, words = slab_bytes / 4;
-    uint32_t *so = reinterpret_cast<uint32_t *>(slab + (size_t)b * slab_bytes);
-    const uint32_t *cw = reinterpret_cast<const uint32_t *>(cands + (size_t)b * maxfreqs);
-    const int n = npk[b];
-    for (int w = tid; w < words; w += 256) {
       uint32_t v = 0;
       if (w == 0) v = (uint32_t)n;
       else if (w >= 4 && w < 4 + K * 12) { const int k = (w - 4) / 12; v = (k < n && k < maxfreqs) ? cw[w - 4] : 0u; }
@@ -1000,24 +798,19 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots, int njig) {
   };
   if (c->fast_now) {
     switch (stage) {
-#if defined(UWSPR_FOLD_STEP_WAVES) && UWSPR_FOLD_STEP_WAVES
-#define K5S_T(n) (n)
-#else
-#define K5S_T(n) 64
-#endif
-      case 1: go(k5_fold_step<1, true>, K5S_T(320)); break;
-      case 2: go(k5_fold_step<2, true>, K5S_T(320)); break;
-      case 3: go(k5_fold_step<3, true>, K5S_T(128)); break;
-      case 4: go(k5_fold_step<4, true>, K5S_T(320)); break;
-      default: go(k5_fold_step<5, true>, K5S_T(320)); break;
+      case 1: go(k5_fold_step<1, true>, 320); break;
+      case 2: go(k5_fold_step<2, true>, 320); break;
+      case 3: go(k5_fold_step<3, true>, 128); break;
+      case 4: go(k5_fold_step<4, true>, 320); break;
+      default: go(k5_fold_step<5, true>, 320); break;
     }
   } else {
     switch (stage) {
-      case 1: go(k5_fold_step<1>, K5S_T(320)); break;
-      case 2: go(k5_fold_step<2>, K5S_T(320)); break;
-      case 3: go(k5_fold_step<3>, K5S_T(128)); break;
-      case 4: go(k5_fold_step<4>, K5S_T(320)); break;
-      default: go(k5_fold_step<5>, K5S_T(320)); break;
+      case 1: go(k5_fold_step<1>, 320); break;
+      case 2: go(k5_fold_step<2>, 320); break;
+      case 3: go(k5_fold_step<3>, 128); break;
+      case 4: go(k5_fold_step<4>, 320); break;
+      default: go(k5_fold_step<5>, 320); break;
     }
   }
 }
@@ -1036,17 +829,6 @@ __global__ void k_keep_try0(const dev_hyp *__restrict__ h5, const float4 *__rest
 void launch_keep_try0(uwspr_ctx *c, int nslots, int njig) {
   dev_hyp *h5 = c->d_hyps + (size_t)nslots * UWSPR_NJIG;
   hipLaunchKernelGGL(k_keep_try0, dim3(nslots), dim3(192), 0, c->stream, h5, c->d_p, (float4 *)c->d_pwin, njig, nslots);
-}
-
-// stage 5's fold and the record in one launch (staged form; option "fold5" = 0 keeps the two launches of rounds 1-4)
-void launch_fold5_finish(uwspr_ctx *c, int nslots, int njig) {
-  prof_scope ps(c, UWSPR_K_FOLD, (int64_t)nslots * njig);
-  dev_hyp *h5 = c->d_hyps + (size_t)nslots * UWSPR_NJIG;
-  uint8_t *slab = c->cands_from_fdr ? c->next_slab : nullptr;
-  hipLaunchKernelGGL(k5_fold5_finish<9>, dim3(nslots), dim3(256), 0, c->stream, c->d_state, h5, (const float4 *)c->d_p,
-                     (const float4 *)c->d_pwin, c->cur_dout, nslots, njig, c->cur_cands, c->cur_npk, c->fc.maxfreqs,
-                     c->sched_per_frame, c->next_slab_K, slab);
-  if (slab) c->next_slab_done = true;
 }
 
 void launch_sched_finish(uwspr_ctx *c, int nslots, int njig) {

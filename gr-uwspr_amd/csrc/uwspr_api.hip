@@ -103,7 +103,6 @@ static const struct { const char *name; int dflt, lo, hi; } kOptions[UWSPR_NOPT]
     {"sched_stamps", 0, 0, 1},      // diagnostics: phase times of the fused kernel (uwspr_debug_sched_stamps)
     {"sched_grid", 0, 0, 65536},    // fused kernel: workgroups (0: one per CU)
     {"dist_force_comm", 0, 0, 1},   // tests: a one-rank communicator is really created
-    {"fold5", 1, 0, 1},             // staged form: stage 5's soft fold + the record as one launch (0: the two launches of rounds 1-4)
     {"frontend", 0, 0, 1},          // K0: 0 the flowgraph's GNU Radio chain as one polyphase FIR (grc:303-400,840-956,1767-1808), 1 compact single stage
 };
 
@@ -906,11 +905,8 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
       launch_fold_step(c, s + 1, (int)nslots, njig);   // fold of stage s + transition to stage s+1
       c->fast_now = false;
     } else {
-      if (c->opt[UWSPR_OPT_FOLD5]) launch_fold5_finish(c, (int)nslots, njig);
-      else {
-        launch_fold(c, h, c->d_p, H, c->d_sync, c->d_sym, (const float4 *)c->d_pwin, njig);
-        launch_sched_finish(c, (int)nslots, njig);
-      }
+      launch_fold(c, h, c->d_p, H, c->d_sync, c->d_sym, (const float4 *)c->d_pwin, njig);
+      launch_sched_finish(c, (int)nslots, njig);
       if (lazy) launch_keep_try0(c, (int)nslots, njig);   // what uwspr_demod_resume starts from
     }
   }

@@ -26,7 +26,6 @@ enum {
   UWSPR_OPT_SCHED_STAMPS,       // diagnostics: phase times of the fused kernel
   UWSPR_OPT_SCHED_GRID,         // fused kernel: workgroups (0 = one per CU)
   UWSPR_OPT_DIST_FORCE_COMM,    // tests: a one-rank communicator is really created
-  UWSPR_OPT_FOLD5,              // staged form: 1 (default) stage 5's soft fold + k_sched_finish as one launch
   UWSPR_OPT_FRONTEND,           // K0 taps: 0 the flowgraph's three-stage GNU Radio chain (default), 1 the compact single stage
   UWSPR_NOPT
 };
@@ -279,7 +278,6 @@ void launch_fold_step(uwspr_ctx *c, int stage, int ncand, int njig = UWSPR_NJIG)
 void launch_pack_slabs(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t *npk,
                        const uwspr_demod_out *dout, int per_frame, int K, uint8_t *slab, int B);
 void launch_sched_finish(uwspr_ctx *c, int ncand, int njig = UWSPR_NJIG);
-void launch_fold5_finish(uwspr_ctx *c, int nslots, int njig);
 // the whole schedule in one launch (k6_sched.hip); njig = mode-2 tries to produce (17 = all)
 void launch_sched_fused(uwspr_ctx *c, const float *frames, int B, const uwspr_candidate *cands,
                         const int32_t *npk, int cand_stride, int per_frame, uwspr_demod_out *out,

@@ -310,7 +310,6 @@ def test_schedule_forms_are_identical(G, frames, vec):
                  {"sched": 0, "stage_kernels": 1},
                  {"sched": 0, "stage_kernels": 1, "reuse": 0},
                  {"sched": 0, "stage_kernels": 1, "phasor_tables": 0},
-                 {"sched": 0, "stage_kernels": 1, "fold5": 0},         # stage 5's fold and the record as two launches
                  {"sched": 0, "stage_kernels": 2},
                  {"sched": 0, "stage_kernels": 2, "reuse": 0},
                  {"sched": 0, "stage_kernels": 2, "rows_mask": 5},     # rows form for S0 and S3 only
