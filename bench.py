@@ -51,6 +51,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
   kernels       HIP-event time per kernel family per step (single stream).
   lazy_s5       the same step with uwspr_set_tries(1): only the first jiggered shift.
   sweep         (N=1) BASELINE configs[2]: 1024 frames x 200 (freq,lag,drift) hypotheses.
+  configs4_n1   (N=1) BASELINE configs[4]: the reference's recording + AWGN, -20 .. -30 dB, decoded fraction and frames/s
+                end to end (K0 front-end + search + host Fano), GPU beside the CPU path (tools/snr_sweep.py).
+  host_pointer_legs  the batch handed over as host buffers (pageable / page-locked): 10 calls each, min / median / max.
 """
 import argparse
 import json
@@ -75,10 +78,20 @@ FP32_NOFMA_PEAK_TOPS = 78.6               # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz
 NBATCH = 5                                # distinct batches the steps rotate over
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(frames_np, budget_s=12.0):
-    """Oracle (CPU restatement) on a bounded sample: FDR over all candidates +
-    the schedule for the top candidate, one frame per worker thread (the C code
-    is re-entrant and ctypes releases the GIL)."""
+    """Oracle (CPU restatement) on a bounded sample, timed per stage as SURVEY 8(d) asks: spectrogram (+ spectrum
+    statistics and peak pick), coarse search over ALL candidates, fine schedule S0..S5 with its 17 soft-symbol vectors
+    for the top candidate.  One frame per worker thread (the C code is re-entrant and ctypes releases the GIL)."""
     from concurrent.futures import ThreadPoolExecutor
     import oracle_py as O
     O.lib()
@@ -89,10 +102,17 @@ def cpu_baseline(frames_np, budget_s=12.0):
 
     def one(args):
         w, b = args
-        c = fdrs[w].transform(frames_np[b])
-        if len(c):
-            O.demod_candidate(c[0], 1500, frames_np[b])
-        return 1
+        f = fdrs[w]
+        t0 = time.perf_counter()
+        ps = f.spectrogram(frames_np[b])
+        cands = f.peaks(f.stats(ps)[2])
+        t1 = time.perf_counter()
+        found = [f.search(ps, c)[0] for c in cands]
+        t2 = time.perf_counter()
+        if found:
+            O.demod_candidate(found[0], 1500, frames_np[b])
+        t3 = time.perf_counter()
+        return t1 - t0, t2 - t1, t3 - t2
 
     t0 = time.time()
     one((0, 0))
@@ -101,12 +121,19 @@ def cpu_baseline(frames_np, budget_s=12.0):
     n = int(max(ncores, budget_s * ncores / per))      # ~budget_s seconds of wall time
     t0 = time.time()
     with ThreadPoolExecutor(ncores) as ex:
-        list(ex.map(one, [(i % ncores, i % nb) for i in range(n)]))
+        parts = list(ex.map(one, [(i % ncores, i % nb) for i in range(n)]))
     dt = time.time() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": ncores, "kind": "port",
-            "sample": "%d frame-passes over %d of the benchmark's frames (oracle FDR over all candidates + "
-                      "S0..S5 schedule with 17 soft-symbol vectors for the top candidate), %d threads, "
-                      "%.1f s wall = %.0f core-seconds" % (n, nb, ncores, dt, dt * ncores)}
+    st = np.array(parts).sum(axis=0)
+    return {"value": n / dt, "unit": "frames/s", "cores": ncores, "kind": "port", "cpu_model": cpu_model(),
+            "frames_per_s_per_core": n / float(st.sum()),
+            "stage_core_seconds": {"spectrogram_and_peaks": float(st[0]), "coarse_search": float(st[1]),
+                                   "fine_schedule": float(st[2])},
+            "stage_ms_per_frame_one_core": {"spectrogram_and_peaks": 1e3 * float(st[0]) / n,
+                                            "coarse_search": 1e3 * float(st[1]) / n,
+                                            "fine_schedule": 1e3 * float(st[2]) / n},
+            "sample": "%d frame-passes over %d of the benchmark's frames (oracle spectrogram + peaks, coarse search over "
+                      "all candidates, S0..S5 schedule with 17 soft-symbol vectors for the top candidate), %d threads, "
+                      "%.1f s wall = %.0f core-seconds" % (n, nb, ncores, dt, float(st.sum()))}
 
 
 def parse_args():
@@ -549,22 +576,46 @@ def main():
     # the same batch handed over as HOST buffers (what a GNU Radio block does per PDU batch):
     # H2D of the frames + D2H of every result, PCIe inclusive; never `value`
     host_rate = None
-    if frames_cpu is not None:
-        ctx.pipeline_batch(frames_cpu, max_per_frame=1)
-        t2 = time.perf_counter()
-        for _ in range(3):
-            ctx.pipeline_batch(frames_cpu, max_per_frame=1)
-        host_rate = 3 * B / (time.perf_counter() - t2)
-    # ... from PAGE-LOCKED host memory (uwspr_host_alloc / any pinned buffer): one DMA per batch
     host_pinned_rate = None
+    host_legs_detail = None
     if frames_cpu is not None:
+        def host_leg(buf, calls=10):
+            ctx.pipeline_batch(buf, max_per_frame=1)          # untimed: allocations, first touch
+            ts = []
+            for _ in range(calls):
+                t2 = time.perf_counter()
+                ctx.pipeline_batch(buf, max_per_frame=1)
+                ts.append(time.perf_counter() - t2)
+            r = sorted(B / t for t in ts)
+            return {"calls": calls, "frames_per_s": {"min": r[0], "median": float(np.median(r)), "max": r[-1]},
+                    "GB_per_s_h2d_median": B * 360000 / float(np.median(ts)) / 1e9}
+        pageable = host_leg(frames_cpu)
+        # ... from PAGE-LOCKED host memory: torch's pinned allocator, and the library's own uwspr_host_alloc
         pinned = torch.from_numpy(frames_cpu).pin_memory()
-        pn = pinned.numpy()
-        ctx.pipeline_batch(pn, max_per_frame=1)
-        t2 = time.perf_counter()
-        for _ in range(3):
-            ctx.pipeline_batch(pn, max_per_frame=1)
-        host_pinned_rate = 3 * B / (time.perf_counter() - t2)
+        pinned_torch = host_leg(pinned.numpy())
+        hp = G.host_alloc(frames_cpu.nbytes) if hasattr(G, "host_alloc") else None
+        pinned_lib = None
+        if hp is not None:
+            hview = np.frombuffer(hp, dtype=np.float32).reshape(frames_cpu.shape)
+            hview[:] = frames_cpu
+            pinned_lib = host_leg(hview)
+            del hview
+            G.host_free(hp)
+        host_rate = pageable["frames_per_s"]["median"]
+        host_pinned_rate = pinned_torch["frames_per_s"]["median"]
+        numa = {}
+        try:
+            import glob
+            numa["gpu_numa_nodes"] = sorted({open(q).read().strip() for q in glob.glob("/sys/class/drm/card*/device/numa_node")})
+            numa["cpus_allowed"] = len(os.sched_getaffinity(0))
+            numa["numa_nodes_online"] = open("/sys/devices/system/node/online").read().strip()
+        except OSError:
+            pass
+        host_legs_detail = {"pageable": pageable, "pinned_torch": pinned_torch, "pinned_uwspr_host_alloc": pinned_lib,
+                            "placement": numa,
+                            "what": "uwspr_pipeline_batch on a HOST buffer of %d frames (92 MB up, records back), PCIe "
+                                    "inclusive; 10 timed calls each; a page-locked buffer is read by one DMA (uwspr_api.hip: "
+                                    "upload), a pageable one goes through the runtime's staging" % B}
     # ---- end to end through the pipelined C-ABI driver (uwspr_pipe_*): lazy schedule || D2H of the records
     # || Fano on the persistent host pool || resume of what try 0 did not decode; results collected on the
     # host.  (a) decoded: the HBM-resident benchmark batches, every frame decodable -- "frames decoded/s";
@@ -761,6 +812,7 @@ def main():
             "lazy_s5": lazy,
             "host_pointer_frames_per_s_pcie_inclusive": host_rate,
             "host_pinned_pointer_frames_per_s_pcie_inclusive": host_pinned_rate,
+            "host_pointer_legs": host_legs_detail,
             "end_to_end_decoded": e2e,
             "host_stream_pcie_inclusive": stream_leg,
             "host_tail_fano": host_tail,
@@ -819,6 +871,23 @@ def main():
         sweep["grid_equals_flat_bitwise"] = bool(torch.equal(grid_sync, sync_t))
         result["sweep"] = sweep
 
+    # ---- BASELINE configs[4] on this one GPU: the reference's recording + AWGN at -20 .. -30 dB, end to end (host audio
+    # -> K0 = the flowgraph's front-end chain -> FDR -> S0..S5 -> records to the host -> Fano + unpack), decoded fraction
+    # and frames/s, the CPU path (oracle search + the same host tail, no front-end) beside it on a bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu and not args.no_host_legs and not strong:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import snr_sweep
+        sw = snr_sweep.run(seeds=64, cpu_seeds=8, quiet=True)
+        result["configs4_n1"] = {
+            "what": "BASELINE configs[4] at N = 1: examples/150613_1920.wav (tests/golden/150613_1920_int16.npz) + AWGN, "
+                    "64 noisy copies per SNR handed over as HOST audio (5.76 MB each, PCIe inclusive), up to 4 candidates per "
+                    "frame through the schedule, Fano + unpack on the host pool; `gpu_lazy` = uwspr_set_tries(1) + "
+                    "uwspr_demod_resume (the reference's early exit); CPU = oracle FDR + schedule + the same host tail on the "
+                    "first 8 frames of each SNR, threads as stated, no front-end; never `value`",
+            "native_snr_db": sw["native_snr_db"], "front_end": sw["front_end"],
+            "rows": [{k: r[k] for k in ("snr_db", "frames", "decoded", "other_decodes", "gpu_equals_cpu", "gpu_frames_per_s",
+                                         "gpu_lazy_frames_per_s", "cpu_frames_per_s", "cpu_frames", "cpu_threads",
+                                         "lazy_records_resumed")} for r in sw["rows"]]}
     if rank == 0:
         result["cpu_baseline"] = cpu_baseline(frames_cpu[:256]) if frames_cpu is not None else None
         print(json.dumps(result))

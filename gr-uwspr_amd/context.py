@@ -502,6 +502,22 @@ def unpack_message(message7):
 FRONTEND_GRC, FRONTEND_COMPACT = 0, 1
 
 
+def host_alloc(nbytes):
+    """uwspr_host_alloc: page-locked host memory as a writable ctypes byte array (np.frombuffer it); release with
+    host_free."""
+    ptr = C.c_void_p()
+    rc = N.lib().uwspr_host_alloc(C.c_size_t(nbytes), C.byref(ptr))
+    if rc:
+        raise N.UwsprError(rc, "uwspr_host_alloc(%d)" % nbytes)
+    buf = (C.c_uint8 * nbytes).from_address(ptr.value)
+    buf._uwspr_ptr = ptr.value
+    return buf
+
+
+def host_free(buf):
+    N.lib().uwspr_host_free(C.c_void_p(buf._uwspr_ptr))
+
+
 def frontend_design(mode=FRONTEND_GRC, stage=0):
     """uwspr_frontend_design: stage 0 -> (complex128 composite taps g, read-ahead D) of the K0 front-end
     y[m] = sum_k g[k] x[32 m + D - k]; stages 1..3 (grc mode) -> the band-pass, low-pass and resampler designs."""

@@ -4,7 +4,7 @@ committed as tests/golden/150613_1920_int16.npz) + AWGN over an SNR sweep, decod
 to end: K0 front-end -> FDR -> S0..S5 schedule (GPU) -> deinterleave + Fano + unpack
 (host), beside the CPU path (oracle kernels + the same host tail) on the same frames.
 
-usage: snr_sweep.py [seeds_per_snr] [--json out.json]
+usage: snr_sweep.py [seeds_per_snr] [--json out.json]      (bench.py calls run() for its configs4_n1 key)
 Prints one row per SNR: decode rate of `VE3EMB FN42 33`, GPU and CPU decode sets equal?,
 GPU and CPU seconds.  SNR is referred to 2500 Hz like WSPR reports; the recording's own
 SNR is estimated from its 375 S/s spectrum and noise is added up to the target.
@@ -61,9 +61,10 @@ def cpu_decode(fdr, frame):
     return texts
 
 
-def main():
-    seeds = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 8
-    jpath = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+def run(seeds=8, cpu_seeds=None, quiet=False):
+    """The sweep; the CPU leg (and the GPU == CPU comparison) covers the first cpu_seeds frames of every SNR."""
+    cpu_seeds = seeds if cpu_seeds is None else min(cpu_seeds, seeds)
+    say = (lambda *a: None) if quiet else print
     x = np.load(os.path.join(ROOT, "tests", "golden", "150613_1920_int16.npz"))["x"].astype(np.float32) / 32768.0
     ctx = G.Context()
     lazy = G.Context()           # the reference's own early exit: try 0 only, the rest on demand
@@ -71,8 +72,12 @@ def main():
     O.lib(); O.pr3()
     nw = min(16, len(os.sched_getaffinity(0)))
     fdrs = [O.FDR() for _ in range(nw)]
-    clean = ctx.frontend(x[None])
-    cands, out = ctx.pipeline_batch(clean, max_per_frame=PER)
+    # the recording's own SNR is a property of the recording: estimated once through the WIDE compact front-end (the
+    # flowgraph's chain passes 1500 +- 10 Hz only: no noise-reference band is left beside the signal)
+    wide = G.Context(options={"frontend": G.FRONTEND_COMPACT})
+    clean = wide.frontend(x[None])
+    cands, out = wide.pipeline_batch(clean, max_per_frame=PER)
+    wide.close()
     f1 = None
     for j in range(min(PER, len(cands[0]))):
         if decode_texts(out[0, j]) == WANT:
@@ -81,7 +86,7 @@ def main():
     assert f1 is not None, "the clean recording must decode"
     ps, n0 = estimate_native(clean[0], f1)
     native = 10 * np.log10(ps / (n0 * 2500.0))
-    print("recording: %s at %+.2f Hz, native SNR %.1f dB in 2500 Hz" % (WANT, f1, native))
+    say("recording: %s at %+.2f Hz, native SNR %.1f dB in 2500 Hz" % (WANT, f1, native))
     rows = []
     for snr in SNRS:
         n0_target = ps / (2500.0 * 10 ** (snr / 10.0))
@@ -119,23 +124,34 @@ def main():
         tl = time.time() - t0
         t0 = time.time()
         with ThreadPoolExecutor(nw) as ex:
-            cpu_texts = list(ex.map(lambda a: cpu_decode(fdrs[a % nw], frames[a]), range(seeds)))
+            cpu_texts = list(ex.map(lambda a: cpu_decode(fdrs[a % nw], frames[a]), range(cpu_seeds)))
         tc = time.time() - t0
         ok = sum(WANT in t for t in gpu_texts)
         false_dec = sum(len([u for u in t if u != WANT]) for t in gpu_texts)
-        same = gpu_texts == cpu_texts and lazy_texts == cpu_texts
+        same = gpu_texts[:cpu_seeds] == cpu_texts and lazy_texts[:cpu_seeds] == cpu_texts and gpu_texts == lazy_texts
         rows.append({"snr_db": snr, "frames": seeds, "decoded": ok, "other_decodes": false_dec,
                      "gpu_equals_cpu": same, "gpu_s": tg, "gpu_lazy_s": tl, "lazy_records_resumed": resumed,
-                     "records": int((out_l["worth_a_try"] != 0).sum()), "cpu_s": tc, "cpu_threads": nw})
-        print("SNR %5.1f dB: %2d/%d decoded, %d other decodes, GPU==lazy==CPU %s, GPU %.1f ms eager / %.1f ms lazy "
+                     "records": int((out_l["worth_a_try"] != 0).sum()), "cpu_s": tc, "cpu_frames": cpu_seeds,
+                     "cpu_threads": nw, "gpu_frames_per_s": seeds / tg, "gpu_lazy_frames_per_s": seeds / tl,
+                     "cpu_frames_per_s": cpu_seeds / tc})
+        say("SNR %5.1f dB: %2d/%d decoded, %d other decodes, GPU==lazy==CPU %s, GPU %.1f ms eager / %.1f ms lazy "
               "(%d of %d records resumed) (host audio in, front-end + search + Fano), CPU %.1f ms on %d threads "
               "(search + Fano, no front-end)"
               % (snr, ok, seeds, false_dec, same, 1e3 * tg, 1e3 * tl, resumed, rows[-1]["records"], 1e3 * tc, nw))
+    ctx.close()
+    lazy.close()
+    return {"recording": "examples/150613_1920.wav", "native_snr_db": float(native), "front_end": "K0, option frontend = 0 (the flowgraph's GNU Radio chain)",
+            "candidates_per_frame": PER, "rows": rows}
+
+
+def main():
+    seeds = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 8
+    jpath = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+    res = run(seeds)
     if jpath:
-        json.dump({"recording": "examples/150613_1920.wav", "native_snr_db": native, "rows": rows},
-                  open(jpath, "w"), indent=1)
-    print("mismatches:", sum(not r["gpu_equals_cpu"] for r in rows))
-    return 0 if all(r["gpu_equals_cpu"] for r in rows) else 1
+        json.dump(res, open(jpath, "w"), indent=1)
+    print("mismatches:", sum(not r["gpu_equals_cpu"] for r in res["rows"]))
+    return 0 if all(r["gpu_equals_cpu"] for r in res["rows"]) else 1
 
 
 if __name__ == "__main__":
