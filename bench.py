@@ -239,8 +239,17 @@ def main():
     B = D.local_count(args.total_frames, rank, world) if strong else args.frames
     Bmax = D.local_count(args.total_frames, 0, world) if strong else B     # equal-sized (padded) shards
     nb = NBATCH if B * 360000 * NBATCH < 40e9 else max(1, int(40e9 // (B * 360000)))
-    batches = [G.synth.make_frames_torch(B, dev, seed=0xC0FFEE + 7919 * rank + 104729 * k, snr_db=args.snr)
-               for k in range(nb)]
+    # Small strong-scaling runs (the rehearsal test, tests/test_dist.py): frame b of a batch is a function of
+    # its GLOBAL index, whatever the number of ranks, so the gathered slabs of an N-rank run can be compared
+    # byte for byte with the one-rank run's (`gathered_slabs_sha256`).  At configs[3]'s size every rank makes
+    # its own shard from its own seed (a global batch of 65 536 frames is 23.6 GB).
+    global_frames = strong and args.total_frames <= 4096
+    if global_frames:
+        batches = [G.synth.make_frames_torch(args.total_frames, dev, seed=0xC0FFEE + 104729 * k, snr_db=args.snr)
+                   [rank::world].contiguous() for k in range(nb)]
+    else:
+        batches = [G.synth.make_frames_torch(B, dev, seed=0xC0FFEE + 7919 * rank + 104729 * k, snr_db=args.snr)
+                   for k in range(nb)]
     K = args.steps
 
     # The HIP streams are created (and used) ONCE, before any context: a stream created after other
@@ -421,6 +430,15 @@ def main():
     for _ in range(max(1, args.repeats)):
         dt, t_enq, gathered = region(lanes, K)
         reps.append((dt, t_enq))
+    gathered_sha = None
+    if rank == 0 and global_frames and gathered is not None:
+        # [world, K * Bmax, SLAB] -> per step, global frame order (b = local * G + rank), padding rows dropped
+        import hashlib
+        gs = gathered.view(world, K, Bmax, D.SLAB_BYTES).cpu()
+        hh = hashlib.sha256()
+        for k in range(K):
+            hh.update(D.restore_order(gs[:, k], args.total_frames).contiguous().numpy().tobytes())
+        gathered_sha = hh.hexdigest()
     gather_checked = None
     if abi_ctx is not None:          # once, outside the timed regions: the two gathers give the same bytes
         ref = D.gather_slabs(slab_ring.view(K * Bmax, D.SLAB_BYTES), dst=0)
@@ -786,7 +804,8 @@ def main():
                        "rehearsal_ranks_share_devices": bool(rehearsal), "backend": backend, "devices": min(ndev, world),
                        "devices_visible": ndev, "device_name": torch.cuda.get_device_name(local),
                        "rccl_version": rccl_version(torch),
-                       "gather": gather_how, "gather_equals_torch_gather": gather_checked},
+                       "gather": gather_how, "gather_equals_torch_gather": gather_checked,
+                       "gathered_slabs_sha256": gathered_sha},
             "roofline": {"kernel": "k6_sched" if fused else "k4_* (6 launches)", "bound": "valu_fp32_nofma",
                          "achieved": achieved_tops, "peak": FP32_NOFMA_PEAK_TOPS, "unit": "Top/s",
                          "frac": achieved_tops / FP32_NOFMA_PEAK_TOPS,

@@ -1,4 +1,4 @@
-// k4_common.h -- arithmetic shared by the tone-correlation kernels (k4_tonecorr.hip, k4_rows.hip).
+// k4_common.h -- arithmetic shared by the tone-correlation kernels (k4_tonecorr.hip, k4_pair.hip).
 // Reference: sync_and_demodulate_impl.cc:186-211.
 #pragma once
 
@@ -19,7 +19,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // dispatcher puts on one CU, the youngest is starved while the others run and then finishes alone, two wavefronts on
 // each SIMD.  Rotating the issue priority over the three from chunk to chunk lets them finish together.  `turn` counts
 // the chunks; the class is the position of the workgroup in its CU's queue.  (s_setprio takes an immediate.)
-// Used by k4_fpack (k4_rows.hip rotates the same way every fourth chunk).  In k4_lag0 and k4_ring it bought < 1 % alone and cost 0.1-0.3 % of the three-stream
+// Used by k4_fpack.  In k4_lag0 and k4_ring it bought < 1 % alone and cost 0.1-0.3 % of the three-stream
 // rate (profiles/r04_prio_rotation_ab.txt), so they stay at the default priority.
 #ifndef UWSPR_K4_PRIO_ROTATION
 #define UWSPR_K4_PRIO_ROTATION 1

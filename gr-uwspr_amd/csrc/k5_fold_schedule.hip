@@ -382,15 +382,11 @@ __device__ __forceinline__ int ptab_set(const cand_state &st, int set, float cen
 __device__ __forceinline__ int ptab_select(const cand_state &st, int set, float f0, float drift, bool on) {
   return ptab_index(st, set, f0, drift, on) + 1;
 }
-__device__ __forceinline__ void emit_row(dev_row *r, bool on, int frame, int L0, uint32_t mask, int tab) {
-  r->frame = on ? frame : -1; r->L0 = L0; r->mask = mask; r->tab = tab;
-}
 
 __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
                              const int32_t *__restrict__ npk, int cand_stride, int B,
                              int per_frame, float cf, cand_state *__restrict__ state,
-                             dev_hyp *__restrict__ hyps, dev_grp *__restrict__ grps, float2 *__restrict__ ptab,
-                             dev_row *__restrict__ rows, int all_a) {
+                             dev_hyp *__restrict__ hyps, dev_grp *__restrict__ grps, float2 *__restrict__ ptab) {
   UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   // one wavefront per slot: every lane derives the same state (lane 0 writes it), lanes 0..19 build table set A
   const int slot = blockIdx.x;
@@ -422,9 +418,8 @@ __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
   // two differ in the sign of a zero.
   st.tabA_f = f0; st.tabB_f = 0.0f; st.tabB_ok = 0;
   st.tabA_ok = (ptab != nullptr && on && (st.m_type != UWSPR_LINEAR || st.drift1 == 0.0f)) ? 1 : 0;
-  // (all five only when a kernel reads them: the rows form's S1; S0 reads the middle one)
-  if (st.tabA_ok && all_a) ptab_build(ptab + (size_t)slot * kPtabPerSlot * kPtabFloat2, 5, 0, f0, 0.25f, st.m_type, st.drift1, st.slmc);
-  else if (st.tabA_ok) ptab_build(ptab + ((size_t)slot * kPtabPerSlot + 2) * kPtabFloat2, 1, 2, f0, 0.25f, st.m_type, st.drift1, st.slmc);
+  // (only the middle one of the five is read: S0; k4_fpack generates S1's phasors itself)
+  if (st.tabA_ok) ptab_build(ptab + ((size_t)slot * kPtabPerSlot + 2) * kPtabFloat2, 1, 2, f0, 0.25f, st.m_type, st.drift1, st.slmc);
   if (threadIdx.x != 0) return;
   state[slot] = st;
   dev_hyp *h = hyps + (size_t)slot * 5;
@@ -435,7 +430,6 @@ __global__ void k_sched_init(const uwspr_candidate *__restrict__ cands,
   }
   emit_group(&grps[slot], st, on, f0, st.drift1, slot * 5, lags, 5);
   grps[slot].nvalid |= ptab_select(st, 0, f0, st.drift1, on) << 16;
-  emit_row(&rows[slot], on, st.frame, lags[0], 0x1fu, ptab_index(st, 0, f0, st.drift1, on));
 }
 
 template <int STAGE>
@@ -447,7 +441,7 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
                                                 uwspr_candidate *__restrict__ cent,
                                                 int32_t *__restrict__ cframe, bool reuse, int team = 0,
                                                 int njig = UWSPR_NJIG, int *wsrc = nullptr, bool tabs = false,
-                                                bool fast = false, dev_row *__restrict__ rows = nullptr) {
+                                                bool fast = false) {
   // *wsrc (written by team 0): the input hypothesis whose tone magnitudes are now those of the state's
   // (f1, shift1, drift1) -- the stage winner -- or -1: the winner is the hypothesis that was marked known
   // (its magnitudes are the ones already kept) or nobody won.  The workgroup copies them to the slot's kept
@@ -473,7 +467,6 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     for (int q = 0; q < 5; q++)
       emit(&ho[q], st, live, st.shift1, st.f1 + (float)(q - 2) * 0.25f, st.drift1, q == 2 && st.cknown);
     emit_centre(&cent[slot], &cframe[slot], st, live);
-    if (rows) emit_row(&rows[slot], live, st.frame, st.shift1, st.cknown ? 0x1bu : 0x1fu, ptab_set(st, 0, st.f1, st.drift1, live));
   } else if (STAGE == 2) {
     // after S1 -> S2 (cc:423-433): linear only, drift1 +- 0.5 at (f1, shift1)
     if (live) {
@@ -515,7 +508,6 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     st.tabB_f = f0;
     st.tabB_ok = (tabs && st.worth && (st.m_type != UWSPR_LINEAR || st.drift1 == 0.0f)) ? 1 : 0;
     grps[slot].nvalid |= ptab_select(st, 1, f0, st.drift1, st.worth != 0) << 16;
-    if (rows) emit_row(&rows[slot], st.worth != 0, st.frame, lags[0], st.cknown ? 0x1bu : 0x1fu, ptab_index(st, 1, f0, st.drift1, st.worth != 0));
   } else if (STAGE == 4) {
     // after S3 -> S4 (cc:449-452): f = f1 + ifreq*0.05
     if (st.worth) {
@@ -528,7 +520,6 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
       emit(&ho[q], st, st.worth != 0, st.shift1, st.f1 + (float)(q - 2) * 0.05f, st.drift1,
            q == 2 && st.cknown);
     emit_centre(&cent[slot], &cframe[slot], st, st.worth != 0);
-    if (rows) emit_row(&rows[slot], st.worth != 0, st.frame, st.shift1, st.cknown ? 0x1bu : 0x1fu, ptab_set(st, 1, st.f1, st.drift1, st.worth != 0));
   } else {
     // after S4 -> S5 (cc:457-468): 17 jiggered shifts, mode 2
     if (st.worth) {
@@ -541,10 +532,6 @@ __device__ __forceinline__ void sched_step_body(int slot, cand_state *__restrict
     // reference's arithmetic, so try 0 is correlated again there)
     const bool known0 = reuse && !fast && st.worth && st.sync1 > -1e30f;
     st.cknown = known0 ? 1 : 0;
-    // rows form (eager tries only): m = 0..16 ascending, shift1 - 64 + 8 m; m = 8 is try 0
-    if (rows && team == 0)
-      emit_row(&rows[slot], st.worth != 0 && njig >= UWSPR_NJIG, st.frame, st.shift1 - 64, known0 ? 0x1feffu : 0x1ffffu,
-               ptab_index(st, 1, st.f1, st.drift1, st.worth != 0));
     if (team < njig) {
       const int idt = team;
       int ii = (idt + 1) / 2;
@@ -609,8 +596,7 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
                              const float4 *__restrict__ p, float *__restrict__ sync,
                              dev_hyp *__restrict__ hout, dev_grp *__restrict__ grps,
                              uwspr_candidate *__restrict__ cent, int32_t *__restrict__ cframe, int nslots,
-                             int reuse, int njig, float4 *__restrict__ pwin, float2 *__restrict__ ptab,
-                             dev_row *__restrict__ rows) {
+                             int reuse, int njig, float4 *__restrict__ pwin, float2 *__restrict__ ptab) {
   UWSPR_SET_PRIO(UWSPR_SMALL_PRIO);
   constexpr int NIN = STAGE == 3 ? 2 : 5;
   __shared__ k5_wave_lds L[FAST ? 1 : NIN];
@@ -631,9 +617,9 @@ __global__ void k5_fold_step(cand_state *__restrict__ state, const dev_hyp *__re
   __syncthreads();
   if (STAGE == 5) {
     if (threadIdx.x < UWSPR_NJIG + 3)
-      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x, njig, &s_wsrc, ptab != nullptr, FAST, rows);
+      sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, (int)threadIdx.x, njig, &s_wsrc, ptab != nullptr, FAST);
   } else if (threadIdx.x == 0) {
-    sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, 0, njig, &s_wsrc, ptab != nullptr, FAST, rows);
+    sched_step_body<STAGE>(slot, state, hin, sy, hout, grps, cent, cframe, reuse != 0, 0, njig, &s_wsrc, ptab != nullptr, FAST);
   }
   __syncthreads();
   if (STAGE == 3 && ptab && threadIdx.x < 64) {   // table set B around the f1 the fine stages start from
@@ -779,7 +765,7 @@ void launch_sched_init(uwspr_ctx *c, const uwspr_candidate *cands, const int32_t
   prof_scope ps(c, UWSPR_K_SCHED, nslots);
   hipLaunchKernelGGL(k_sched_init, dim3(nslots), dim3(64), 0, c->stream, cands,
                      npk, cand_stride, B, per_frame, (float)c->p.cf, c->d_state, c->d_hyps, c->d_grps,
-                     c->use_ptab ? c->d_ptab : nullptr, c->d_rows, c->opt[UWSPR_OPT_STAGE_KERNELS] == 2 ? 1 : 0);
+                     c->use_ptab ? c->d_ptab : nullptr);
 }
 
 // hyps of consecutive stages ping-pong between the two halves of d_hyps;
@@ -794,7 +780,7 @@ void launch_fold_step(uwspr_ctx *c, int stage, int nslots, int njig) {
   auto go = [&](auto kern, int threads) {
     hipLaunchKernelGGL(kern, g, dim3(threads), 0, c->stream, c->d_state, hin, c->d_p, c->d_sync, hout, c->d_grps,
                        c->d_cent, c->d_cent_frame, nslots, reuse, njig, (float4 *)c->d_pwin,
-                       c->use_ptab ? c->d_ptab : nullptr, c->d_rows);
+                       c->use_ptab ? c->d_ptab : nullptr);
   };
   if (c->fast_now) {
     switch (stage) {

@@ -90,11 +90,10 @@ static float slm_frequency_drift(double V1, double V2, int p1, int p2, float cf,
 // variable UWSPR_OPTIONS="name=value,name=value".  Nothing else in the library reads the environment.
 static const struct { const char *name; int dflt, lo, hi; } kOptions[UWSPR_NOPT] = {
     {"sched", 1, 0, 1},             // 1: fused kernel k6_sched; 0: staged launches
-    {"stage_kernels", 1, 0, 2},     // staged form: 0 flat kernel everywhere (the reference form), 1 packed / ring kernels, 2 rows form
+    {"stage_kernels", 1, 0, 1},     // staged form: 0 flat kernel everywhere (the reference form), 1 packed / ring kernels
     {"reuse", 1, 0, 1},             // the hypothesis that repeats the previous stage's winner is not correlated again
     {"phasor_tables", 1, 0, 1},     // lag stages read their phasors from per-slot tables
     {"fast_search", 0, 0, 1},       // stages S0..S4 with fused multiply-adds and shuffle-tree sums (NOT the reference's arithmetic)
-    {"rows_mask", 31, 0, 31},       // stage_kernels = 2: bit per stage kind S0,S1,S3,S4,S5 that takes the rows form
     {"k4_t", 0, 0, 4},              // flat kernel: tones per lane (0: by size)
     {"k5_lanes", -1, -1, 1},        // fold: -1 by size, 0 wave form, 1 lanes form
     {"k1_rows", 0, 0, 348},         // spectrogram: rows per wavefront walk (0: default)
@@ -200,11 +199,6 @@ extern "C" int uwspr_ctx_create(const uwspr_params *p, int device, uwspr_ctx **o
   c->d_cands = nullptr; c->d_npk = nullptr; c->d_work = nullptr; c->last_B = 0; c->num_cus = 256;
   c->grid_cap = 0; c->cap_grid_bytes = 0; c->d_syncgrid = nullptr;
   c->cap_hyps = 0; c->d_hyps = nullptr; c->cap_grps = 0; c->d_grps = nullptr;
-  c->cap_rows = 0; c->d_rows = nullptr;
-  {   // wavefronts per tone of a rows workgroup, per stage kind S0,S1,S3,S4,S5
-    static const int dflt[5] = {2, 2, 2, 2, 2};
-    for (int k = 0; k < 5; k++) c->rows_hs[k] = dflt[k];
-  }
   c->cap_cent = 0; c->d_cent = nullptr; c->d_cent_frame = nullptr; c->cap_abi_hyps = 0; c->d_abi_hyps = nullptr;
   c->cap_p = 0; c->d_p = nullptr; c->cap_sync = 0; c->d_sync = nullptr;
   c->cap_sym = 0; c->d_sym = nullptr; c->cap_state = 0; c->d_state = nullptr;
@@ -375,7 +369,7 @@ extern "C" void uwspr_ctx_destroy(uwspr_ctx *c) {
   (void)uwspr_dist_finalize(c);
   if (c->own_stream) { (void)hipStreamSynchronize(c->own_stream); }
   void *bufs[] = {c->d_window, c->d_twiddle, c->d_k3_tile, c->d_off, c->d_umap, c->d_fe_taps, c->d_audio, c->d_frames, c->d_ps, c->d_psavg, c->d_smraw,
-                  c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_rows, c->d_cent,
+                  c->d_smspec, c->d_noise, c->d_cands, c->d_npk, c->d_work, c->d_syncgrid, c->d_hyps, c->d_grps, c->d_cent,
                   c->d_abi_hyps, c->d_p, c->d_sync, c->d_sym, c->d_state, c->d_dout, c->d_slab, c->d_tabs, c->d_counter, c->d_sched_stamps, c->d_pwin, c->d_ptab, c->d_need, c->d_stream_frames, c->d_tmpc, c->d_tmpn};
   for (void *b : bufs) if (b) (void)hipFree(b);
   c->ring.close();
@@ -853,7 +847,6 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
   }
   if ((rc = ensure(c, &c->d_hyps, &c->cap_hyps, 2 * nslots * UWSPR_NJIG))) return rc;
   if ((rc = ensure(c, &c->d_grps, &c->cap_grps, 3 * nslots))) return rc;
-  if ((rc = ensure(c, &c->d_rows, &c->cap_rows, nslots))) return rc;
   // centres (48 B) followed by their frame indices (4 B): 13 int32 per slot in one buffer
   if ((rc = ensure(c, &c->d_cent, &c->cap_cent, (nslots * 13 + 11) / 12 + 1))) return rc;
   c->d_cent_frame = reinterpret_cast<int32_t *>(c->d_cent + nslots);
@@ -868,15 +861,13 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
   launch_sched_init(c, dcands, dnpk, cand_stride, B, per_frame);
   const bool lazy = njig < UWSPR_NJIG;   // only tries idt < njig of stage 5, packed njig per slot
   // Staged form, "stage_kernels": 1 (default) = S0 sample-major on packed rows (k4_lag0), S1 / S4 packed frequency stage
-  // (k4_fpack), S3 / S5 LDS ring (k4_ring), S2 mirrored pairs (k4_dpair); 2 = the rows form (k4_rows.hip) for the stage kinds of "rows_mask";
+  // (k4_fpack), S3 / S5 LDS ring (k4_ring), S2 mirrored pairs (k4_dpair);
   // 0 = the flat kernel for every stage (the independent reference form of the equivalence tests).
-  static const int rows_kind[6] = {UWSPR_ROWS_S0, UWSPR_ROWS_S1, -1, UWSPR_ROWS_S3, UWSPR_ROWS_S4, UWSPR_ROWS_S5};
   const int sk = c->opt[UWSPR_OPT_STAGE_KERNELS];
   for (int s = 0; s < 6; s++) {
     c->fast_now = c->fast_search && s < 5;   // S5 (the soft symbols) is always the reference's arithmetic
     const int H = (int)(nslots * (s == 5 ? njig : hpc[s]));
     const dev_hyp *h = half[s & 1];
-    const bool rows = sk == 2 && c->use_ptab && s != 2 && ((c->opt[UWSPR_OPT_ROWS_MASK] >> rows_kind[s]) & 1);
     if (sk == 0 || (lazy && s == 5)) launch_tonecorr(c, dframes, B, h, H, c->d_p);   // (lazy S5: few, unrelated lags)
 #if !defined(UWSPR_S2_PAIRS) || UWSPR_S2_PAIRS   // (0: experiment builds, the flat kernel as before)
     else if (s == 2) {
@@ -889,7 +880,6 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
 #else
     else if (s == 2) launch_tonecorr(c, dframes, B, h, H, c->d_p);
 #endif
-    else if (rows) launch_tonecorr_rows(c, dframes, B, rows_kind[s], h, (int)nslots, H, c->d_p);
     else if (s == 1 || s == 4) launch_tonecorr_fstage(c, dframes, B, h, (int)nslots, H, c->d_p);
     else if (s == 3) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)nslots, 5, 16, H, c->d_p, 1);
     else if (s == 5) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, 8, H, c->d_p, 3);

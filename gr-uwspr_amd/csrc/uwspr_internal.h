@@ -13,11 +13,10 @@
 // Options of a context, by index (names and defaults: uwspr_api.hip: kOptions; ABI: uwspr_set_option).
 enum {
   UWSPR_OPT_SCHED = 0,          // 1 fused kernel (default), 0 staged launches
-  UWSPR_OPT_STAGE_KERNELS,      // staged form: 1 packed / ring kernels (default), 0 flat kernel everywhere, 2 rows form
+  UWSPR_OPT_STAGE_KERNELS,      // staged form: 1 packed / ring kernels (default), 0 flat kernel everywhere
   UWSPR_OPT_REUSE,              // 1 (default): the hypothesis that repeats the previous stage's winner is not correlated again
   UWSPR_OPT_PHASOR_TABLES,      // 1 (default)
   UWSPR_OPT_FAST_SEARCH,        // 0 (default)
-  UWSPR_OPT_ROWS_MASK,          // stage_kernels = 2: bit per stage kind S0,S1,S3,S4,S5 (default 31)
   UWSPR_OPT_K4_T,               // flat kernel: tones per lane (0 = by size)
   UWSPR_OPT_K5_LANES,           // fold form: -1 by size (default), 0 wave form, 1 lanes form
   UWSPR_OPT_K1_ROWS,            // spectrogram rows per wavefront walk (0 = default)
@@ -96,17 +95,6 @@ struct dev_grp {
 };
 static_assert(sizeof(dev_grp) == 64, "dev_grp is one 64-byte record");
 
-// What the rows form of K4 (k4_rows.hip) computes for a slot in the stage being launched; written by the
-// schedule kernels next to the stage's dev_hyp records.
-struct dev_row {
-  int32_t frame;     // <0: dead slot
-  int32_t L0;        // smallest lag of the stage: hypothesis h has lag L0 + 8 dk8(h)
-  uint32_t mask;     // bit h: hypothesis h is computed (known / unused ones are not)
-  int32_t tab;       // phasor table within the slot (frequency stages: the first of the set's five), -1: the
-                     // frequency depends on the symbol, every lane runs its own recurrences
-};
-enum { UWSPR_ROWS_S0 = 0, UWSPR_ROWS_S1 = 1, UWSPR_ROWS_S3 = 2, UWSPR_ROWS_S4 = 3, UWSPR_ROWS_S5 = 4 };
-
 // per-candidate refinement state kept in HBM between schedule stages
 struct cand_state {
   int32_t frame;       // <0: empty slot
@@ -183,8 +171,6 @@ struct uwspr_ctx {
   int grid_cap; size_t cap_grid_bytes; float *d_syncgrid;  // [B][grid_cap][ntot]
 
   size_t cap_hyps; uwspr::dev_hyp *d_hyps;
-  size_t cap_rows; uwspr::dev_row *d_rows;   // [nslots] of the stage being launched (k4_rows.hip)
-  int rows_hs[5];        // hypothesis subsets (wavefronts per tone) of a rows workgroup, per stage kind
   size_t cap_grps; uwspr::dev_grp *d_grps;
   size_t cap_cent; uwspr_candidate *d_cent; int32_t *d_cent_frame;   // per-slot grid centres (S1/S2/S4)
   size_t cap_abi_hyps; uwspr_hyp *d_abi_hyps;
@@ -257,8 +243,6 @@ void launch_tonecorr(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hy
 // stage S2 (hyps 2 s, 2 s + 1 = the two drift tries of slot s): the slots whose tries mirror each other (k4_pair.hip)
 void launch_tonecorr_dpair(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int nslots, float4 *p);
 void launch_tonecorr_lag0(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int nslots,
-                          int64_t nhyps, float4 *p);
-void launch_tonecorr_rows(uwspr_ctx *c, const float *frames, int B, int kind, const dev_hyp *hyps, int nslots,
                           int64_t nhyps, float4 *p);
 void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int nslots,
                             int64_t nhyps, float4 *p);

@@ -314,7 +314,7 @@ int uwspr_set_tries(uwspr_ctx *ctx, int ntries);
  * bytes -- except "fast_search":
  *   "sched"          1 (default): the whole S0..S5 schedule of a candidate in one workgroup; 0: one launch
  *                    per stage (what uwspr_pipe_* uses from three lanes up)
- *   "stage_kernels"  staged form: 1 (default) packed / ring kernels, 2 the rows form, 0 the flat kernel for
+ *   "stage_kernels"  staged form: 1 (default) packed / ring / pair kernels, 0 the flat kernel for
  *                    every stage -- an independent form the equivalence tests compare the others with
  *   "reuse"          1 (default): the hypothesis that repeats the previous stage's winner
  *                    (sync_and_demodulate_impl.cc:416-452 evaluate it again and get the same number) is skipped
@@ -324,7 +324,7 @@ int uwspr_set_tries(uwspr_ctx *ctx, int ntries);
  *                    tolerance), integer results and soft symbols were identical on every frame tried
  *                    (tests/test_gpu_fast_search.py); stage 5 -- the soft symbols -- and every other entry
  *                    point stay exact.  Staged form only (it sets "sched" 0).
- * Further names ("rows_mask", "k4_t", "k5_lanes", "sched_stamps", "sched_grid", "dist_force_comm", and the
+ * Further names ("k4_t", "k5_lanes", "sched_stamps", "sched_grid", "dist_force_comm", and the
  * creation-time "k1_rows", "k3_tile", "k3_pitch") are diagnostics: DESIGN.md section 9.  The one environment
  * variable the library reads, UWSPR_OPTIONS="name=value,...", presets options for every context the process
  * creates.  Unknown names: UWSPR_ERR_ARG. */

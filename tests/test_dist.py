@@ -124,3 +124,54 @@ def test_c_abi_gather_equals_the_torch_gather_on_one_rank(G, monkeypatch):
             c.dist_gather(slab, slab, root=0)                # not initialised
     finally:
         c.close()
+
+
+def _bench_line(extra, timeout=420):
+    """One `bench.py` run as the driver starts it (a child process; rank 0's JSON line on stdout)."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--repeats", "1",
+           "--total-frames", "50", "--sched", "staged", "--streams", "2", "--no-cpu", "--no-sweep", "--no-lazy",
+           "--no-host-legs"] + extra
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_gathers_the_one_rank_slabs():
+    """The first thing the driver's multi-GPU run executes and nothing else did: `bench.py --gpus 2` spawning
+    its ranks (here both on the one device: --rehearsal, gloo), round-robin shards of 50 frames per step (25 + 25;
+    with three ranks the shards would be padded), the end-of-region slab gather and the order restore.  The
+    frames of a small --total-frames run are a function of their global index, so rank 0's gathered slabs in
+    global frame order must be byte for byte the one-rank run's."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("the rehearsal shares ONE device between the ranks")
+    one = _bench_line(["--gpus", "1"])
+    two = _bench_line(["--gpus", "2", "--rehearsal"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert one["config"]["gather"] == "none (one rank)"
+    assert two["config"]["gather"] == "torch.distributed (gloo)"
+    assert two["config"]["backend"] == "gloo"
+    assert two["config"]["rehearsal_ranks_share_devices"] is True
+    assert one["config"]["rehearsal_ranks_share_devices"] is False
+    assert two["config"]["parallelism"] == "dp2" and two["scaling"] == "strong"
+    assert two["config"]["frames_per_gpu"] == 25 and one["config"]["frames_per_gpu"] == 50
+    sha = one["config"]["gathered_slabs_sha256"]
+    assert sha and len(sha) == 64
+    assert two["config"]["gathered_slabs_sha256"] == sha
+    # without --rehearsal more ranks than devices is an error, not a silent time-slice
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu", "--no-sweep", "--no-lazy", "--no-host-legs"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
+    assert r.returncode == 2 and b"--rehearsal" in r.stderr

@@ -1,5 +1,5 @@
 """Byte-equality of the staged schedule under options (GPU box):
-    python3 tools/env_equiv.py stage_kernels=2 [reuse=0 ...]
+    python3 tools/env_equiv.py stage_kernels=0 [reuse=0 ...]
 runs uwspr_pipeline_batch + uwspr_demod_batch on seeded frames with the default options and with the given
 ones (fresh contexts, staged form) and compares every output byte."""
 import os

@@ -3,7 +3,5 @@
 set -x
 python3 tools/soak_parity.py 2000 10 0 91000                                             # fused (default)
 UWSPR_OPTIONS=sched=0 python3 tools/soak_parity.py 2000 10 0 92000                       # staged, packed / ring kernels
-UWSPR_OPTIONS=sched=0,stage_kernels=2 python3 tools/soak_parity.py 2000 10 0 93000       # staged, rows form
-UWSPR_OPTIONS=sched=0,stage_kernels=2 python3 tools/soak_parity.py 1500 40 2 94000       # rows form, drifting candidates (per-lane recurrences)
 UWSPR_OPTIONS=sched=0 python3 tools/soak_parity.py 1500 40 2 95000                       # packed kernels, drifting candidates (flat-kernel fallback of S0)
 UWSPR_OPTIONS=sched=0,stage_kernels=0 python3 tools/soak_parity.py 1000 20 4 96000       # flat kernel everywhere
