@@ -111,6 +111,18 @@ class Context:
     def synchronize(self):
         self._chk(self.L.uwspr_synchronize(self.h))
 
+    def debug_snr_db(self, x):
+        """diagnostics: 10 * log10f(x) as K2 computes a candidate's `snr` (FDR_impl.cc:303); x, result: float32 CUDA tensors"""
+        import torch
+        out = torch.empty_like(x)
+        f = self.L.uwspr_debug_snr_db
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+        f.restype = C.c_int
+        torch.cuda.current_stream().synchronize()
+        self._chk(f(self.h, C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), x.numel()))
+        self.synchronize()
+        return out
+
     # -- front-end ---------------------------------------------------------
     def frontend(self, audio):
         """12 kS/s real audio [B, nin] -> frames [B, fl, 2] at 375 S/s (uwspr_frontend_batch)."""

@@ -15,6 +15,77 @@
 
 namespace uwspr {
 
+// FDR_impl.cc:303 takes `log10(smspec[j])` of a float: g++ resolves it to log10f, and log10f is NOT correctly rounded
+// -- its last bit is whatever the host's libm computes.  This is glibc 2.35's (the image's; Ubuntu 22.04) algorithm,
+// operation for operation: sysdeps/ieee754/flt-32/e_log10f.c (k = exponent, mantissa scaled into [sqrt(1/2), sqrt 2),
+// y*log10_2lo + ivln10*logf(x) + y*log10_2hi in binary32) around sysdeps/ieee754/flt-32/e_logf.c (16-entry table
+// of 1/c and log c, third-degree polynomial, all in binary64, rounded once) with its table logf_data.c.  On x86-64
+// libm selects a build of logf with or without fused multiply-adds by the CPU; both give the same binary32 result for
+// EVERY argument (tests/test_log10_gap.py walks all 2^31 - 2^23 positive ones against the host's libm with both), so
+// the plain form below is the one restated.  With it the `snr` field is the reference's to the bit wherever the
+// reference runs on that libm; a libm with another log10f (glibc >= 2.40 rounds correctly) differs in the last
+// bit on a few per cent of the arguments, as the binary64 route of rounds 1-4 did.
+__device__ const double kLogfTab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+    {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+    {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+    {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+    {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+    {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+
+__device__ __forceinline__ float logf_glibc235(float x) {
+  uint32_t ix = __float_as_uint(x);
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {       // zero, subnormal, negative, inf, nan
+    if (ix * 2 == 0) return -__builtin_inff();
+    if (ix == 0x7f800000u) return x;
+    if ((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return __builtin_nanf("");
+    ix = __float_as_uint(x * 0x1p23f);
+    ix -= 23u << 23;
+  }
+  const uint32_t tmp = ix - 0x3f330000u;
+  const int i = (int)((tmp >> 19) & 15u);
+  const int k = (int32_t)tmp >> 23;
+  const uint32_t iz = ix - (tmp & (0x1ffu << 23));
+  const double invc = kLogfTab[i][0], logc = kLogfTab[i][1];
+  const double z = (double)__uint_as_float(iz);
+  const double r = z * invc - 1.0;
+  const double y0 = logc + (double)k * 0x1.62e42fefa39efp-1;
+  const double r2 = r * r;
+  double y = 0x1.5575b0be00b6ap-2 * r + -0x1.ffffef20a4123p-2;
+  y = -0x1.00ea348b88334p-2 * r2 + y;
+  y = y * r2 + (y0 + r);
+  return (float)y;
+}
+
+__device__ __forceinline__ float log10f_glibc235(float x) {
+  const float two25 = 3.3554432000e+07f, ivln10 = 4.3429449201e-01f, log10_2hi = 3.0102920532e-01f,
+              log10_2lo = 7.9034151668e-07f;
+  int32_t hx = (int32_t)__float_as_uint(x), k = 0;
+  if (hx < 0x00800000) {
+    if ((hx & 0x7fffffff) == 0) return -two25 / fabsf(x);
+    if (hx < 0) return (x - x) / (x - x);
+    k -= 25;
+    x *= two25;
+    hx = (int32_t)__float_as_uint(x);
+  }
+  if (hx >= 0x7f800000) return x + x;
+  k += (hx >> 23) - 127;
+  const int32_t i = (int32_t)(((uint32_t)k & 0x80000000u) >> 31);
+  hx = (hx & 0x007fffff) | ((0x7f - i) << 23);
+  const float y = (float)(k + i);
+  const float z = y * log10_2lo + ivln10 * logf_glibc235(__uint_as_float((uint32_t)hx));
+  return z + y * log10_2hi;
+}
+
+// diagnostics (tests/test_log10_gap.py): the `snr` expression of cc:303 over an array
+__global__ void k_debug_snr_db(const float *__restrict__ x, float *__restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = 10.0f * log10f_glibc235(x[i]);
+}
+
 // 1024 threads: the frame's 60 KB tile comes into LDS with 16-byte loads, four per thread (with 256 threads and
 // 4-byte loads the copy alone was most of the kernel's 15 us); the later steps are strided loops over <= 512 items
 constexpr int K2_THREADS = 1024;
@@ -119,8 +190,8 @@ __global__ __launch_bounds__(K2_THREADS) void k2_spectrum(
       for (int q = 0; q < j; q++) pos += flag[q];
       if (pos < f.maxfreqs) {
         pk_freq[pos] = (float)(j - f.hpbm) * f.df;
-        // cc:303: 10*log10(smspec) as a binary32 value
-        pk_snr[pos] = 10.0f * (float)log10((double)sm[j]);
+        // cc:303: 10*log10(smspec) -- log10f, this libm's (see log10f_glibc235)
+        pk_snr[pos] = 10.0f * log10f_glibc235(sm[j]);
         atomicAdd(&npk_s, 1);
       }
     }
@@ -161,3 +232,11 @@ void launch_spectrum(uwspr_ctx *c, int B) {
 }
 
 }  // namespace uwspr
+
+// diagnostics (not part of the ABI header): out[i] = 10 * log10f(x[i]) as K2 computes a candidate's snr; device pointers
+extern "C" int uwspr_debug_snr_db(uwspr_ctx *c, const float *x_dev, float *out_dev, long long n) {
+  if (!c || !x_dev || !out_dev || n < 0) return UWSPR_ERR_ARG;
+  if (n == 0) return UWSPR_OK;
+  hipLaunchKernelGGL(uwspr::k_debug_snr_db, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, x_dev, out_dev, n);
+  return hipGetLastError() == hipSuccess ? UWSPR_OK : UWSPR_ERR_HIP;
+}

@@ -89,8 +89,12 @@ def lib():
         L.orc_fdr_search.argtypes = [C.POINTER(Fdr), fp, C.c_void_p, fp]
         L.orc_fdr_transform.argtypes = [C.POINTER(Fdr), fp, C.c_void_p]
         L.orc_fdr_transform.restype = C.c_int
-        L.orc_log10_gap.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
-        L.orc_log10_gap.restype = C.c_long
+        L.orc_log10f_walk.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32)]
+        L.orc_log10f_walk.restype = C.c_long
+        L.orc_log10f_glibc235.argtypes = [C.c_float, C.c_int]
+        L.orc_log10f_glibc235.restype = C.c_float
+        L.orc_snr_db.argtypes = [fp, fp, C.c_long]
+        L.orc_snr_db.restype = None
         L.orc_slm_frequency_drift.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int,
                                               C.c_float, C.c_float]
         L.orc_slm_frequency_drift.restype = C.c_float

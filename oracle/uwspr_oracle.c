@@ -533,18 +533,98 @@ void orc_demod_candidate(const orc_candidate *cand_in, int cf, const float *id,
   }
 }
 
-/* test support: see uwspr_oracle.h */
-long orc_log10_gap(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride, uint32_t *first_bad) {
+/* ---- test support for FDR_impl.cc:303: see uwspr_oracle.h ----
+ * glibc 2.35 (Ubuntu GLIBC 2.35-0ubuntu3.x, this image's libm): sysdeps/ieee754/flt-32/e_logf.c with the table of
+ * sysdeps/ieee754/flt-32/logf_data.c (LOGF_TABLE_BITS 4, LOGF_POLY_ORDER 4), and sysdeps/ieee754/flt-32/e_log10f.c
+ * around it, restated operation for operation.  `fma` != 0: the multiply-adds of e_logf.c fused as the compiler fuses
+ * them in the build libm selects on CPUs with FMA (sysdeps/x86_64/fpu/multiarch/e_logf.c). */
+static const double glibc_logf_tab[16][2] = {
+    {0x1.661ec79f8f3bep+0, -0x1.57bf7808caadep-2}, {0x1.571ed4aaf883dp+0, -0x1.2bef0a7c06ddbp-2},
+    {0x1.49539f0f010bp+0, -0x1.01eae7f513a67p-2},  {0x1.3c995b0b80385p+0, -0x1.b31d8a68224e9p-3},
+    {0x1.30d190c8864a5p+0, -0x1.6574f0ac07758p-3}, {0x1.25e227b0b8eap+0, -0x1.1aa2bc79c81p-3},
+    {0x1.1bb4a4a1a343fp+0, -0x1.a4e76ce8c0e5ep-4}, {0x1.12358f08ae5bap+0, -0x1.1973c5a611cccp-4},
+    {0x1.0953f419900a7p+0, -0x1.252f438e10c1ep-5}, {0x1p+0, 0x0p+0},
+    {0x1.e608cfd9a47acp-1, 0x1.aa5aa5df25984p-5},  {0x1.ca4b31f026aap-1, 0x1.c5e53aa362eb4p-4},
+    {0x1.b2036576afce6p-1, 0x1.526e57720db08p-3},  {0x1.9c2d163a1aa2dp-1, 0x1.bc2860d22477p-3},
+    {0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2},  {0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2}};
+static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+static float glibc235_logf(float x, int use_fma) {
+  const double Ln2 = 0x1.62e42fefa39efp-1;
+  const double A0 = -0x1.00ea348b88334p-2, A1 = 0x1.5575b0be00b6ap-2, A2 = -0x1.ffffef20a4123p-2;
+  uint32_t ix = f2u(x), tmp, iz;
+  int i, k;
+  double z, r, r2, y, y0, invc, logc;
+  if (ix == 0x3f800000u) return 0.0f;
+  if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
+    if (ix * 2 == 0) return -INFINITY;
+    if (ix == 0x7f800000u) return x;
+    if ((ix & 0x80000000u) || ix * 2 >= 0xff000000u) return NAN;
+    ix = f2u(x * 0x1p23f);
+    ix -= 23u << 23;
+  }
+  tmp = ix - 0x3f330000u;
+  i = (int)((tmp >> 19) % 16);
+  k = (int32_t)tmp >> 23;
+  iz = ix - (tmp & (0x1ffu << 23));
+  invc = glibc_logf_tab[i][0];
+  logc = glibc_logf_tab[i][1];
+  z = (double)u2f(iz);
+  if (use_fma) {
+    r = fma(z, invc, -1.0);
+    y0 = fma((double)k, Ln2, logc);
+    r2 = r * r;
+    y = fma(A1, r, A2);
+    y = fma(A0, r2, y);
+    y = fma(y, r2, y0 + r);
+  } else {
+    r = z * invc - 1;
+    y0 = logc + (double)k * Ln2;
+    r2 = r * r;
+    y = A1 * r + A2;
+    y = A0 * r2 + y;
+    y = y * r2 + (y0 + r);
+  }
+  return (float)y;
+}
+
+float orc_log10f_glibc235(float x, int use_fma) {
+  const float two25 = 3.3554432000e+07f, ivln10 = 4.3429449201e-01f, log10_2hi = 3.0102920532e-01f,
+              log10_2lo = 7.9034151668e-07f;
+  float y, z;
+  int32_t i, k = 0, hx = (int32_t)f2u(x);
+  if (hx < 0x00800000) {
+    if ((hx & 0x7fffffff) == 0) return -two25 / fabsf(x);
+    if (hx < 0) return (x - x) / (x - x);
+    k -= 25;
+    x *= two25;
+    hx = (int32_t)f2u(x);
+  }
+  if (hx >= 0x7f800000) return x + x;
+  k += (hx >> 23) - 127;
+  i = (int32_t)(((uint32_t)k & 0x80000000u) >> 31);
+  hx = (hx & 0x007fffff) | ((0x7f - i) << 23);
+  y = (float)(k + i);
+  x = u2f((uint32_t)hx);
+  z = y * log10_2lo + ivln10 * glibc235_logf(x, use_fma);
+  return z + y * log10_2hi;
+}
+
+long orc_log10f_walk(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride, int use_fma, uint32_t *first_bad) {
   long bad = 0;
   if (stride == 0) stride = 1;
   for (uint64_t b = lo_bits; b < hi_bits; b += stride) {
-    uint32_t u = (uint32_t)b, ga, gb;
-    float x, a, c;
-    memcpy(&x, &u, 4);
-    a = (float)10 * log10f(x);                      /* the oracle's (and g++'s) form of cc:303 */
-    c = 10.0f * (float)log10((double)x);            /* k2_spectrum.hip */
-    memcpy(&ga, &a, 4); memcpy(&gb, &c, 4);
-    if (ga != gb) { if (!bad && first_bad) *first_bad = u; bad++; }
+    float x = u2f((uint32_t)b);
+    uint32_t ga = f2u(log10f(x)), gb = f2u(orc_log10f_glibc235(x, use_fma));
+    if (ga != gb && !(ga * 2 > 0xff000000u && gb * 2 > 0xff000000u)) {      /* (two NaNs are equal here) */
+      if (!bad && first_bad) *first_bad = (uint32_t)b;
+      bad++;
+    }
   }
   return bad;
+}
+
+void orc_snr_db(const float *x, float *out, long n) {
+  for (long i = 0; i < n; i++) out[i] = (float)10 * log10f(x[i]);          /* cc:303 as the oracle has it (:244) */
 }

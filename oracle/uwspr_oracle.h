@@ -131,10 +131,15 @@ void orc_demod_candidate(const orc_candidate *cand, int cf, const float *id,
 /* sync_and_demodulate_impl.cc:469-474 */
 float orc_symbols_rms(const unsigned char *symbols);
 
-/* Test support for FDR_impl.cc:303 (`10*log10(smspec)`, the binary32 overload): over the binary32 values with bit
- * patterns lo_bits <= b < hi_bits (step `stride`), how many give  log10f(x) != (float)log10((double)x)  -- this libm's
- * log10f against the binary64 route the HIP kernel takes (k2_spectrum.hip).  *first_bad = the first such pattern. */
-long orc_log10_gap(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride, uint32_t *first_bad);
+/* Test support for FDR_impl.cc:303 (`10*log10(smspec)`: the binary32 overload, i.e. the host libm's log10f, which is
+ * not correctly rounded).  The oracle itself calls log10f (uwspr_oracle.c:244).  orc_log10f_glibc235 restates glibc
+ * 2.35's algorithm -- what the HIP kernel computes (k2_spectrum.hip: log10f_glibc235) -- with the multiply-adds of its
+ * logf plain (use_fma 0) or fused (1: the build libm selects on CPUs with FMA); orc_log10f_walk counts the binary32
+ * patterns lo_bits <= b < hi_bits (step `stride`) on which this host's log10f differs from it (*first_bad = the first);
+ * orc_snr_db is cc:303 over an array (the host's log10f). */
+float orc_log10f_glibc235(float x, int use_fma);
+long orc_log10f_walk(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride, int use_fma, uint32_t *first_bad);
+void orc_snr_db(const float *x, float *out, long n);
 
 #ifdef __cplusplus
 }

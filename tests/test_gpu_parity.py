@@ -38,7 +38,8 @@ def cand_equal(a, b, lin_strict=True):
     assert int(a["shift"]) == int(b["shift"])
     assert np.float32(a["freq"]).tobytes() == np.float32(b["freq"]).tobytes()
     assert abs(float(a["sync"]) - float(b["sync"])) <= RTOL * abs(float(b["sync"]))
-    assert abs(float(a["snr"]) - float(b["snr"])) <= RTOL * abs(float(b["snr"])) + 1e-6
+    # cc:303 to the bit: the kernel restates this libm's log10f (tests/test_log10_gap.py)
+    assert np.float32(a["snr"]).tobytes() == np.float32(b["snr"]).tobytes()
     if int(a["m_type"]) == 0:
         da = np.frombuffer(a.tobytes()[24:28], np.float32)[0]
         db = np.frombuffer(b.tobytes()[24:28], np.float32)[0]
