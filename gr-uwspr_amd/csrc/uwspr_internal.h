@@ -26,6 +26,7 @@ enum {
   UWSPR_OPT_SCHED_GRID,         // fused kernel: workgroups (0 = one per CU)
   UWSPR_OPT_DIST_FORCE_COMM,    // tests: a one-rank communicator is really created
   UWSPR_OPT_FRONTEND,           // K0 taps: 0 the flowgraph's three-stage GNU Radio chain (default), 1 the compact single stage
+  UWSPR_OPT_K4_FORMS,           // staged form, bit mask of kernel forms (default: all that won their A/B): bit 0 = S5 register ring
   UWSPR_NOPT
 };
 
@@ -247,7 +248,10 @@ void launch_tonecorr_lag0(uwspr_ctx *c, const float *frames, int B, const dev_gr
 void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int nslots,
                             int64_t nhyps, float4 *p);
 void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
-                          int NL, int step, int64_t nhyps, float4 *p, int groups_per_slot = 1);
+                          int NL, int step, int64_t nhyps, float4 *p, int groups_per_slot = 1, int rest_only = 0);
+// S5's jiggered shifts with the sample pairs in a register ring (k4_jig.hip); untabled groups are left to k4_ring<6,8>
+void launch_tonecorr_jig(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G, int64_t nhyps, float4 *p,
+                         int groups_per_slot);
 // grid form (one centre per frame, shared sample windows); false = does not fit, use the flat path
 bool launch_tonecorr_grid(uwspr_ctx *c, const float *frames, int B, const uwspr_candidate *centres,
                           int nf, const float *df, int ndrift, const float *ddrift, int nlag,

@@ -26,7 +26,7 @@ LIBPATH = os.path.join(LIBDIR, "libuwspr_hip_exp_%s.so" % _EXTRA_TAG if _EXTRA e
 HOSTLIB = os.path.join(LIBDIR, "libuwspr_blocks.so")
 
 SOURCES = ["uwspr_api.hip", "k0_frontend.hip", "k1_spectrogram.hip", "k2_spectrum.hip", "k3_coarse.hip",
-           "k4_tonecorr.hip", "k4_grid.hip", "k4_pair.hip", "k5_fold_schedule.hip", "k6_sched.hip", "pipe.hip", "dist.hip", "host_tail.cpp"]
+           "k4_tonecorr.hip", "k4_grid.hip", "k4_pair.hip", "k4_jig.hip", "k5_fold_schedule.hip", "k6_sched.hip", "pipe.hip", "dist.hip", "host_tail.cpp"]
 HIPFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
             "-fno-slp-vectorize", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fPIC", "-Wall", "-Wno-unused-function"]
 
