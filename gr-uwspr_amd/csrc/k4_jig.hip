@@ -13,8 +13,9 @@
 //
 // Layout as in k4_ring: a wavefront = 16 (group, symbol) pairs x 4 tones, wavefront-private LDS (a ring of four 16-sample
 // slots per pair, filled by the wavefront's own loader; a 16-step slice of the phasor tables per chunk), no workgroup
-// barrier.  Wavefronts whose live groups do not all have a table (drifting linear candidates) are left to k4_ring<6,8>,
-// launched behind this kernel with `rest_only` (not launched at all after this context's own FDR with maxdrift = 0).
+// barrier.  Wavefronts whose live groups do not all have a table (drifting linear candidates -- stage 2 can give ANY
+// candidate a drift of +-0.5 Hz -- : the tone frequency depends on the symbol) run the same walk on per-lane phasor
+// recurrences instead of the table slice.
 // The lag slot that is known (try 0 = the stage-4 winner) or unused (the third group has five tries) is left out by
 // instantiating the walk three times (12 KB of code each: the three run side by side on a CU and fit its instruction
 // cache); a wavefront-uniform branch per lag instead costs the wavefront a dozen scalar instructions per 96 multiply-adds,
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(64 * K4J_WAVES, K4J_OCC) void k4_jig(
   const int tone = lane & 3;
   const bool mineA = pr < sb;
   const int own_i = mineA ? iA0 + pr : pr - sb;
-  // nothing live in this wavefront: zeros for the dead groups' hypotheses, done (k4_ring's rest_only pass skips these too)
+  // nothing live in this wavefront: zeros for the dead groups' hypotheses, done
   if (!okA && !liveB) {   // wave-uniform
     if (g0 + pr < total) {
       const dev_grp &gy = mineA ? A : Bg;
@@ -82,12 +83,15 @@ __global__ __launch_bounds__(64 * K4J_WAVES, K4J_OCC) void k4_jig(
     }
     return;
   }
-  if (!use_tab) return;   // wave-uniform: a live group without a phasor table -> k4_ring<6,8>(rest_only)
-
-  const float2 *tabA = ptab + ((size_t)(gA / gps) * kPtabPerSlot + (max(selA, 1) - 1)) * kPtabFloat2;
-  const float2 *tabB = ptab + ((size_t)((gA + 1) / gps) * kPtabPerSlot + (max(selB, 1) - 1)) * kPtabFloat2;
-  if (!selA) tabA = tabB;     // a dead group's lanes read some valid table (their results are discarded)
-  if (!selB) tabB = tabA;
+  // (a live group without a table -- stage 2 gave the candidate a drift: the tone frequency depends on the symbol -- puts
+  // the wavefront on per-lane phasor recurrences, cc:193-195: TAB = false below)
+  const float2 *tabA = ptab, *tabB = ptab;
+  if (use_tab) {
+    tabA = ptab + ((size_t)(gA / gps) * kPtabPerSlot + (max(selA, 1) - 1)) * kPtabFloat2;
+    tabB = ptab + ((size_t)((gA + 1) / gps) * kPtabPerSlot + (max(selB, 1) - 1)) * kPtabFloat2;
+    if (!selA) tabA = tabB;     // a dead group's lanes read some valid table (their results are discarded)
+    if (!selB) tabB = tabA;
+  }
   // The lag slot nobody needs: slot 2 when it repeats the stage-4 winner (nvalid bit 8) in every live group of the
   // wavefront; else slot 5 when every live group holds at most five tries; else none.
   const bool knownA = !okA || (A.nvalid & 0x100) != 0, knownB = !okB || (Bg.nvalid & 0x100) != 0;
@@ -95,8 +99,9 @@ __global__ __launch_bounds__(64 * K4J_WAVES, K4J_OCC) void k4_jig(
   const bool skip_last = !skip_mid && (!okA || nvA <= 5) && (!liveB || nvB <= 5);
   // everything from here on once per variant of the left-out lag slot (SKIPL: 2 known, 5 unused, -1 none), nothing
   // shared between the three: 12 KB of code each
-  auto body = [&](auto skip_tag) __attribute__((always_inline)) {
+  auto body = [&](auto skip_tag, auto tab_tag) __attribute__((always_inline)) {
   constexpr int SKIPL = decltype(skip_tag)::value;
+  constexpr bool TAB = decltype(tab_tag)::value;       // phasors from the slot's table (else: this lane's recurrence)
   const int l0A = okA ? A.lag[0] : 1 - 256 * iA0;   // dead groups point at safe samples
   const int l0B = okB ? Bg.lag[0] : 1;
 
@@ -161,14 +166,27 @@ __global__ __launch_bounds__(64 * K4J_WAVES, K4J_OCC) void k4_jig(
 #pragma unroll
       for (int j = 0; j < 4; j++) pro[sl][j] = stage[j];
     }
-    load_tab(0);
+    if (TAB) load_tab(0);
 #pragma unroll
     for (int sl = 0; sl <= Q; sl++) {
 #pragma unroll
       for (int j = 0; j < 4; j++) stage[j] = pro[sl][j];
       store_slot(sl);
     }
-    store_tab();
+    if (TAB) store_tab();
+  }
+  // without a table: this lane's tone phasor step (binary64 angle, cc:173-189) and the recurrence state
+  float rc = 1.0f, rs = 0.0f, rcd = 1.0f, rsd = 0.0f;
+  if (!TAB) {
+    const dev_grp &gy = mineA ? A : Bg;
+    const float fp = (gy.m_type == UWSPR_LINEAR)
+                         ? (float)((double)gy.f0 + ((double)gy.drift / 2.0) * ((double)(float)own_i - 81.0) / 81.0)
+                         : gy.f0 + gy.slmc;
+    const float delta = ((float)tone - 1.5f) * 1.46484375f;
+    double sn, cs;
+    sincos(kTwoPiDt * (double)(fp + delta), &sn, &cs);
+    rcd = (float)cs;
+    rsd = (float)sn;
   }
 
   // ring positions of slots c..c+Q as this lane's row addresses (dword offsets into `lds`)
@@ -193,16 +211,24 @@ __global__ __launch_bounds__(64 * K4J_WAVES, K4J_OCC) void k4_jig(
     constexpr int PH = decltype(phase_tag)::value;       // chunk number mod 3: where the register ring stands
     // in flight during the chunk's arithmetic (the last chunks re-fetch the last slot: no branch here)
     load_slot(min(ch + Q + 1, NSLOT - 1));
-    load_tab(min(ch + 1, 15));
+    if (TAB) load_tab(min(ch + 1, 15));
     wave_lds_fence();                      // the slots written so far are visible
-    float4 phn = *reinterpret_cast<const float4 *>(&ptl[trow]);   // (c, s) of steps 2i, 2i + 1: one iteration ahead
+    float4 phn = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (TAB) phn = *reinterpret_cast<const float4 *>(&ptl[trow]);   // (c, s) of steps 2i, 2i + 1: one iteration ahead
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       const int j0 = 8 * PH + i;                          // iteration number mod R (a constant after unrolling)
       const int o = 2 * i + 2 * AH;                       // the new pair's first sample, relative to the chunk
       ring[(j0 + AH) % R] = *reinterpret_cast<const float4 *>(&lds[sa[o >> 4] + 2 * (o & 15)]);
-      const float4 ph = phn;
-      if (i < 7) phn = *reinterpret_cast<const float4 *>(&ptl[trow + 2 * i + 2]);
+      float4 ph = phn;
+      if (TAB) {
+        if (i < 7) phn = *reinterpret_cast<const float4 *>(&ptl[trow + 2 * i + 2]);
+      } else {
+        ph.x = rc; ph.y = rs;
+        k4_rot<false>(rc, rs, rcd, rsd);     // cc:193-195
+        ph.z = rc; ph.w = rs;
+        k4_rot<false>(rc, rs, rcd, rsd);
+      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int l = 0; l < NL; l++) {
@@ -223,7 +249,7 @@ __global__ __launch_bounds__(64 * K4J_WAVES, K4J_OCC) void k4_jig(
     // slot ch is finished with: its position takes slot ch + Q + 1, and the addresses rotate
     wave_lds_fence();
     store_slot(wpos);
-    store_tab();
+    if (TAB) store_tab();
     wpos = (wpos + 1 == M) ? 0 : wpos + 1;
     const int first = sa[0];
 #pragma unroll
@@ -255,9 +281,15 @@ __global__ __launch_bounds__(64 * K4J_WAVES, K4J_OCC) void k4_jig(
         p_out[((long long)(gy.hyp_base + (int)((gy.hmap >> (4 * l)) & 15u)) * UWSPR_NSYM + own_i) * 4 + tone] = 0.0f;
   }
   };
-  if (skip_mid) body(std::integral_constant<int, 2>{});            // wave-uniform
-  else if (skip_last) body(std::integral_constant<int, 5>{});
-  else body(std::integral_constant<int, -1>{});
+  if (use_tab) {                                                                       // wave-uniform, all of it
+    if (skip_mid) body(std::integral_constant<int, 2>{}, std::true_type{});
+    else if (skip_last) body(std::integral_constant<int, 5>{}, std::true_type{});
+    else body(std::integral_constant<int, -1>{}, std::true_type{});
+  } else {
+    if (skip_mid) body(std::integral_constant<int, 2>{}, std::false_type{});
+    else if (skip_last) body(std::integral_constant<int, 5>{}, std::false_type{});
+    else body(std::integral_constant<int, -1>{}, std::false_type{});
+  }
 }
 
 // groups: lags lag[0] + 8 l, l < nvalid <= 6 (the schedule's S5 emitter, eager tries)
@@ -270,7 +302,7 @@ void launch_tonecorr_jig(uwspr_ctx *c, const float *frames, int B, const dev_grp
   const unsigned blocks = (unsigned)((waves + K4J_WAVES - 1) / K4J_WAVES);
   if (gps < 1) gps = 1;
   launch_timed(c, ps, k4_jig, dim3(blocks), dim3(64 * K4J_WAVES), 0, (const float2 *)frames, c->fstride, c->np, B, grps, G,
-               (float *)p, (const float2 *)c->d_ptab, gps);
+               (float *)p, c->use_ptab ? (const float2 *)c->d_ptab : nullptr, gps);
 }
 
 }  // namespace uwspr

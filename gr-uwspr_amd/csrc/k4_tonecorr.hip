@@ -245,7 +245,7 @@ constexpr int K4_PT_STRIDE = 18;   // float2 per (group, tone) row of the slice:
 template <int NL, int STEP, bool FAST = false>
 __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
     const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_grp *__restrict__ grps,
-    int G, float *__restrict__ p_out, const float2 *__restrict__ ptab, int gps, int rest_only) {
+    int G, float *__restrict__ p_out, const float2 *__restrict__ ptab, int gps) {
   constexpr int PPW = 16;
   constexpr int W = (NL - 1) * STEP;       // extra samples beyond the first lag's window
   constexpr int Q = (15 + W) / 16;         // furthest slot a chunk reaches ahead
@@ -285,7 +285,6 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
     if (!selA) tabA = tabB;     // a dead group's lanes read some valid table (their results are discarded)
     if (!selB) tabB = tabA;
   }
-  if (rest_only && (use_tab || (!okA && !liveB))) return;   // wave-uniform: k4_jig has done these (k4_jig.hip: same predicate)
   // nvalid bit 8: lag slot 2 repeats the previous stage's winner, its metric is known and nobody
   // reads its p[] -- skipped when that holds for every live group of the wave (NL == 5 only)
   const bool knownA = !okA || (A.nvalid & 0x100) != 0, knownB = !okB || (Bg.nvalid & 0x100) != 0;
@@ -513,7 +512,7 @@ __global__ __launch_bounds__(64 * K4G_WAVES) void k4_ring(
 
 // lags of every group must be lag[0] + l*step, l < nvalid (the schedule's S3 / S5 emitters)
 void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
-                          int NL, int step, int64_t nhyps, float4 *p, int gps, int rest_only) {
+                          int NL, int step, int64_t nhyps, float4 *p, int gps) {
   if (G <= 0) return;
   const bool r5 = NL == 5 && step == 16, r6 = NL == 6 && step == 8;
   if (!r5 && !r6) return;   // (the schedule emits exactly these two spacings)
@@ -526,9 +525,9 @@ void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_gr
   dim3 blk(64 * K4G_WAVES);
   const float2 *pt = c->use_ptab ? c->d_ptab : nullptr;
   if (gps < 1) gps = 1;
-  if (r5 && c->fast_now) launch_timed(c, ps, (k4_ring<5, 16, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, pt, gps, rest_only);
-  else if (r5) launch_timed(c, ps, (k4_ring<5, 16>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, pt, gps, rest_only);
-  else launch_timed(c, ps, (k4_ring<6, 8>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, pt, gps, rest_only);
+  if (r5 && c->fast_now) launch_timed(c, ps, (k4_ring<5, 16, true>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, pt, gps);
+  else if (r5) launch_timed(c, ps, (k4_ring<5, 16>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, pt, gps);
+  else launch_timed(c, ps, (k4_ring<6, 8>), dim3(blocks), blk, 0, fr, c->fstride, c->np, B, grps, G, po, pt, gps);
 }
 
 

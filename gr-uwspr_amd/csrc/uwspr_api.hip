@@ -883,14 +883,8 @@ static int run_schedule_impl(uwspr_ctx *c, const float *dframes, int B, const uw
 #endif
     else if (s == 1 || s == 4) launch_tonecorr_fstage(c, dframes, B, h, (int)nslots, H, c->d_p);
     else if (s == 3) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)nslots, 5, 16, H, c->d_p, 1);
-    else if (s == 5 && (c->opt[UWSPR_OPT_K4_FORMS] & 1) && c->use_ptab) {
-      // S5: the groups with a phasor table through the register-ring kernel; the others (drifting linear candidates)
-      // through the LDS-ring kernel, which leaves the former alone -- not needed after this context's own FDR with
-      // maxdrift = 0
-      launch_tonecorr_jig(c, dframes, B, c->d_grps, (int)(3 * nslots), H, c->d_p, 3);
-      if (!(c->cands_from_fdr && c->p.maxdrift == 0))
-        launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, 8, H, c->d_p, 3, 1);
-    }
+    else if (s == 5 && (c->opt[UWSPR_OPT_K4_FORMS] & 1))
+      launch_tonecorr_jig(c, dframes, B, c->d_grps, (int)(3 * nslots), H, c->d_p, 3);   // register ring (k4_jig.hip)
     else if (s == 5) launch_tonecorr_ring(c, dframes, B, c->d_grps, (int)(3 * nslots), 6, 8, H, c->d_p, 3);
     else if (c->use_ptab) {
       // S0: the slots whose frequency does not depend on the symbol (they have their phasor table) sample-major;

@@ -248,8 +248,8 @@ void launch_tonecorr_lag0(uwspr_ctx *c, const float *frames, int B, const dev_gr
 void launch_tonecorr_fstage(uwspr_ctx *c, const float *frames, int B, const dev_hyp *hyps, int nslots,
                             int64_t nhyps, float4 *p);
 void launch_tonecorr_ring(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G,
-                          int NL, int step, int64_t nhyps, float4 *p, int groups_per_slot = 1, int rest_only = 0);
-// S5's jiggered shifts with the sample pairs in a register ring (k4_jig.hip); untabled groups are left to k4_ring<6,8>
+                          int NL, int step, int64_t nhyps, float4 *p, int groups_per_slot = 1);
+// S5's jiggered shifts with the sample pairs in a register ring (k4_jig.hip)
 void launch_tonecorr_jig(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int G, int64_t nhyps, float4 *p,
                          int groups_per_slot);
 // grid form (one centre per frame, shared sample windows); false = does not fit, use the flat path

@@ -1112,3 +1112,35 @@ def test_two_contexts_with_different_coarse_tiles(G, oracle, frames):
                     cand_equal(x, e)
     finally:
         a.close(); b.close(); c.close()
+
+
+def test_schedule_forms_agree_on_candidates_that_stage_2_gives_a_drift(G):
+    """Stage 2 (cc:421-441) can give ANY candidate a drift of +-0.5 Hz -- also one from an FDR with maxdrift = 0 -- and from
+    there on its tone frequency depends on the symbol: no phasor table, per-lane recurrences in S3, S4 and S5.  Round 5's
+    first wiring of the register-ring kernel left such groups to a second launch that is skipped after the context's own
+    FDR with maxdrift = 0 (a shortcut that is right for S0, whose candidates have no drift yet); the exact-vs-fast test
+    caught it by luck.  Here: weak and noise-only frames through uwspr_pipeline_batch -- the FDR's own candidates -- in
+    every schedule form, byte for byte, and the drifting records counted."""
+    fr = np.concatenate([G.synth.make_frames(120, seed=0xD21F7, snr_db=-27.0),
+                         G.synth.make_frames(120, seed=0xD21F8, snr_db=-30.0),
+                         (0.5 * np.random.default_rng(77).standard_normal((60, 45000, 2))).astype(np.float32)])
+    outs = {}
+    for name, opts in (("fused", {"sched": 1}), ("staged", {"sched": 0}), ("staged-lds-ring", {"sched": 0, "k4_forms": 0}),
+                       ("staged-flat", {"sched": 0, "stage_kernels": 0, "phasor_tables": 0})):
+        c = G.Context(options=opts)
+        try:
+            cands, out = c.pipeline_batch(fr, max_per_frame=2)
+            outs[name] = (cands, out)
+        finally:
+            c.close()
+    ref = outs["fused"][1]
+    for name in ("staged", "staged-lds-ring", "staged-flat"):
+        assert outs[name][1].tobytes() == ref.tobytes(), name
+    drifting = worth = 0
+    for b in range(len(fr)):
+        for j in range(min(2, len(outs["fused"][0][b]))):
+            r = ref[b, j]
+            drifting += int(float(r["drift1"]) != 0.0)
+            worth += int(r["worth_a_try"]) * int(float(r["drift1"]) != 0.0)
+    print("%d records with a stage-2 drift, %d of them worth a try (their S5 runs without a table)" % (drifting, worth))
+    assert drifting >= 20 and worth >= 3
