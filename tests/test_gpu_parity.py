@@ -366,13 +366,15 @@ def test_schedule_forms_on_random_candidates(G, oracle):
     for name, opts in (("fused", {"sched": 1}),
                        ("staged", {"sched": 0}),
                        ("staged-lds-ring", {"sched": 0, "k4_forms": 0}),
+                       ("staged-no-tables", {"sched": 0, "phasor_tables": 0}),     # every wavefront on per-lane recurrences
+                       ("staged-no-tables-no-reuse", {"sched": 0, "phasor_tables": 0, "reuse": 0}),
                        ("staged-flat", {"sched": 0, "stage_kernels": 0, "phasor_tables": 0})):
         c = G.Context(options=opts)
         try:
             outs[name] = c.demod_batch(frames, cands, max_per_frame=per)
         finally:
             c.close()
-    for name in ("staged", "staged-lds-ring", "staged-flat"):
+    for name in ("staged", "staged-lds-ring", "staged-no-tables", "staged-no-tables-no-reuse", "staged-flat"):
         assert outs[name].tobytes() == outs["fused"].tobytes(), name
     for b, j in ((0, 0), (0, 3), (2, 1), (3, 0), (5, 2)):
         d = oracle.demod_candidate(cands[b][j], 1500, frames[b])
