@@ -5,8 +5,9 @@
 // lag l at steps 2j, 2j + 1 multiplies phasor pair j with sample pair j + 4 l.  k4_ring<6,8> (k4_tonecorr.hip) keeps the
 // group's window in LDS and fetches that sample pair for every lag -- six ds_read_b128 per iteration, each writing four
 // VGPRs through the port the arithmetic writes its results through (DESIGN: an LDS read of 16 bytes costs the SIMD about
-// four arithmetic issue slots), 7 reads per 96 multiply-adds with the phasor pair.  But a sample pair is the same pair for
-// all six lags, at iterations 4 apart: here iteration j fetches ONE new pair (j + 23) into a ring of 24 float4 that the
+// four arithmetic issue slots), 7 reads per 96 multiply-adds with the phasor pair.  (What it buys and what it does not:
+// profiles/r05_k4_jig_ab.txt -- the wavefront's issue stalls go, its third neighbour on the SIMD goes too: 220 VGPRs.)  But a sample pair is the same pair for
+// all six lags, at iterations 4 apart: here iteration j fetches ONE new pair (j + 21) into a ring of 24 float4 that the
 // lags index at compile time (the walk is unrolled over the ring period: 24 iterations = three 16-step chunks): 2 LDS
 // reads per 96 multiply-adds.  Same operands into the same accumulators in the same order as cc:206-207; the phasors
 // are the slot's table (the recurrence of cc:193-195, built once: k5_fold_schedule.hip: ptab_build).
@@ -18,7 +19,7 @@
 // recurrences instead of the table slice.
 // The lag slot that is known (try 0 = the stage-4 winner) or unused (the third group has five tries) is left out by
 // instantiating the walk three times (12 KB of code each: the three run side by side on a CU and fit its instruction
-// cache); a wavefront-uniform branch per lag instead costs the wavefront a dozen scalar instructions per 96 multiply-adds,
+// cache; three more for the recurrence walk, rarely run); a wavefront-uniform branch per lag instead costs the wavefront a dozen scalar instructions per 96 multiply-adds,
 // and a wavefront issues ONE instruction of any kind per 4.5 cycles (measured: 125 -> 152 us).
 #include "k4_common.h"
 
