@@ -280,6 +280,41 @@ def demod_candidate(cand, cf, iq, np_points=None):
     }
 
 
+def cand_diff(a, e):
+    """Fields of a GPU candidate `a` that differ from the oracle's `e` (FDR.transform): what the PDU carries
+    (FDR_impl.cc:414-455), binary32 fields by their bytes.  -> list of field names."""
+    bad = [k for k in ("m_type", "shift") if int(a[k]) != int(e[k])]
+    bad += [k for k in ("freq", "sync", "snr") if np.float32(a[k]).tobytes() != np.float32(e[k]).tobytes()]
+    if int(e["m_type"]) == 1:
+        bad += [k for k in ("V1", "V2", "p1", "p2") if a[k] != e[k]]
+    elif a.tobytes()[24:28] != e.tobytes()[24:28]:      # m_linear.drift
+        bad.append("drift")
+    return bad
+
+
+def record_diff(o, d):
+    """Fields of a GPU record `o` (a `uwspr_demod_out` element) that differ from the oracle's `d` = demod_candidate(...):
+    integers by value, binary32 fields by their BYTES, the soft-symbol vectors of all 17 tries byte for byte (cc:457-482).
+    The one comparison the tests, tools/soak_parity.py and bench.py's `parity_spot_check` share.  -> list of field names."""
+    bad = []
+    if int(o["worth_a_try"]) != int(d["worth_a_try"]):
+        bad.append("worth_a_try")
+    if int(o["shift1"]) != int(d["shift1"]):
+        bad.append("shift1")
+    for k in ("f1", "drift1", "sync1"):
+        if np.float32(o[k]).tobytes() != np.float32(d[k]).tobytes():
+            bad.append(k)
+    if d["worth_a_try"]:
+        if not (np.asarray(o["symbols"]) == d["symbols"]).all():
+            bad.append("symbols")
+        if not (np.asarray(o["jig_shift"]) == d["jig_shift"]).all():
+            bad.append("jig_shift")
+        for k in ("jig_sync", "jig_rms"):
+            if np.asarray(o[k], np.float32).tobytes() != d[k].tobytes():
+                bad.append(k)
+    return bad
+
+
 def deinterleave(symbols):
     s = np.array(symbols, dtype=np.uint8).copy()
     lib().orc_deinterleave(s.ctypes.data_as(C.POINTER(C.c_ubyte)))

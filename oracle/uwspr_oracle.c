@@ -240,8 +240,11 @@ int orc_fdr_peaks(const orc_fdr *f, const float *smspec, orc_candidate *cands) {
         (npk < f->maxfreqs)) {
       memset(&cands[npk], 0, sizeof(orc_candidate));
       cands[npk].freq = (float)(j - f->hpbm) * f->df;
-      /* cc:303: log10(float) resolves to the binary32 overload (g++ >= 6) */
-      cands[npk].snr = (float)10 * log10f(smspec[j]);
+      /* cc:303: log10(float) resolves to the binary32 overload (g++ >= 6), and libm's log10f is not correctly
+       * rounded: its last bit belongs to the C library.  The pinned platform is glibc 2.35 / x86-64 (this image, where
+       * oracle/_ref is built and run); the oracle calls the RESTATEMENT of that log10f, not the host's, so that a host
+       * with another libm changes nothing here (tests/test_log10_gap.py states whether this host's log10f is that one) */
+      cands[npk].snr = (float)10 * orc_log10f_glibc235(smspec[j], 0);
       npk++;
     }
   }
@@ -626,5 +629,5 @@ long orc_log10f_walk(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride, int us
 }
 
 void orc_snr_db(const float *x, float *out, long n) {
-  for (long i = 0; i < n; i++) out[i] = (float)10 * log10f(x[i]);          /* cc:303 as the oracle has it (:244) */
+  for (long i = 0; i < n; i++) out[i] = (float)10 * orc_log10f_glibc235(x[i], 0);   /* cc:303 as orc_fdr_peaks has it */
 }

@@ -132,11 +132,12 @@ void orc_demod_candidate(const orc_candidate *cand, int cf, const float *id,
 float orc_symbols_rms(const unsigned char *symbols);
 
 /* Test support for FDR_impl.cc:303 (`10*log10(smspec)`: the binary32 overload, i.e. the host libm's log10f, which is
- * not correctly rounded).  The oracle itself calls log10f (uwspr_oracle.c:244).  orc_log10f_glibc235 restates glibc
- * 2.35's algorithm -- what the HIP kernel computes (k2_spectrum.hip: log10f_glibc235) -- with the multiply-adds of its
+ * not correctly rounded).  PINNED PLATFORM: glibc 2.35 / x86-64.  Since round 6 the oracle's orc_fdr_peaks calls
+ * orc_log10f_glibc235 (use_fma 0), not the host's log10f: a host with another libm (glibc >= 2.40 rounds log10f
+ * correctly) cannot change the oracle's `snr`.  orc_log10f_glibc235 restates glibc 2.35's algorithm -- what the HIP kernel computes (k2_spectrum.hip: log10f_glibc235) -- with the multiply-adds of its
  * logf plain (use_fma 0) or fused (1: the build libm selects on CPUs with FMA); orc_log10f_walk counts the binary32
  * patterns lo_bits <= b < hi_bits (step `stride`) on which this host's log10f differs from it (*first_bad = the first);
- * orc_snr_db is cc:303 over an array (the host's log10f). */
+ * orc_snr_db is cc:303 over an array, as orc_fdr_peaks has it (the restatement). */
 float orc_log10f_glibc235(float x, int use_fma);
 long orc_log10f_walk(uint32_t lo_bits, uint32_t hi_bits, uint32_t stride, int use_fma, uint32_t *first_bad);
 void orc_snr_db(const float *x, float *out, long n);

@@ -166,6 +166,15 @@ def test_bench_two_rank_rehearsal_gathers_the_one_rank_slabs():
     sha = one["config"]["gathered_slabs_sha256"]
     assert sha and len(sha) == 64
     assert two["config"]["gathered_slabs_sha256"] == sha
+    # three ranks: 50 frames = 17 + 17 + 16, the last shard padded to 17 rows that the order restore drops
+    three = _bench_line(["--gpus", "3", "--rehearsal"])
+    assert three["n_gpus"] == 3 and three["config"]["frames_per_gpu"] == 17
+    assert three["config"]["gathered_slabs_sha256"] == sha
+    # and what the timed lanes left in their buffers is the oracle's (bench.py: parity_spot_check), on the staged form
+    for line in (one, two, three):
+        sc = line["parity_spot_check"]
+        assert sc["equal"] is True and sc["frames"] == 8 and sc["form"] == "staged" and sc["mismatches"] == [], sc
+        assert line["chosen_streams"] == 2 and line["chosen_sched"] == "staged"
     # without --rehearsal more ranks than devices is an error, not a silent time-slice
     import subprocess
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")

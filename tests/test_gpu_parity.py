@@ -1116,13 +1116,14 @@ def test_two_contexts_with_different_coarse_tiles(G, oracle, frames):
         a.close(); b.close(); c.close()
 
 
-def test_schedule_forms_agree_on_candidates_that_stage_2_gives_a_drift(G):
+def test_schedule_forms_agree_on_candidates_that_stage_2_gives_a_drift(G, oracle):
     """Stage 2 (cc:421-441) can give ANY candidate a drift of +-0.5 Hz -- also one from an FDR with maxdrift = 0 -- and from
     there on its tone frequency depends on the symbol: no phasor table, per-lane recurrences in S3, S4 and S5.  Round 5's
     first wiring of the register-ring kernel left such groups to a second launch that is skipped after the context's own
     FDR with maxdrift = 0 (a shortcut that is right for S0, whose candidates have no drift yet); the exact-vs-fast test
     caught it by luck.  Here: weak and noise-only frames through uwspr_pipeline_batch -- the FDR's own candidates -- in
-    every schedule form, byte for byte, and the drifting records counted."""
+    every schedule form, byte for byte, the drifting records counted, and (round 6) EVERY record of the staged form -- the one
+    bench.py times -- against the oracle's demod_candidate (cc:421-441, 457-468), not only against the other forms."""
     fr = np.concatenate([G.synth.make_frames(120, seed=0xD21F7, snr_db=-27.0),
                          G.synth.make_frames(120, seed=0xD21F8, snr_db=-30.0),
                          (0.5 * np.random.default_rng(77).standard_normal((60, 45000, 2))).astype(np.float32)])
@@ -1146,3 +1147,11 @@ def test_schedule_forms_agree_on_candidates_that_stage_2_gives_a_drift(G):
             worth += int(r["worth_a_try"]) * int(float(r["drift1"]) != 0.0)
     print("%d records with a stage-2 drift, %d of them worth a try (their S5 runs without a table)" % (drifting, worth))
     assert drifting >= 20 and worth >= 3
+    cands, staged = outs["staged"]
+    checked = 0
+    for b in range(len(fr)):
+        for j in range(min(2, len(cands[b]))):
+            d = oracle.demod_candidate(cands[b][j], 1500, fr[b])
+            assert oracle.record_diff(staged[b, j], d) == [], (b, j, float(staged[b, j]["drift1"]))
+            checked += int(d["drift1"] != 0.0)
+    assert checked == drifting

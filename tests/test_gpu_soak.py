@@ -10,14 +10,26 @@ import pytest
 from conftest import ROOT
 
 
+# The schedule forms the library can run, each one against the ORACLE record by record: "" is the default of
+# one context (the fused kernel k6_sched); "sched=0" is the staged form -- what bench.py times as `value` and what
+# uwspr_pipe_* runs on three lanes; then the staged form with S5 on the LDS-ring kernel and without the stage-winner reuse.
+FORMS = ["", "sched=0", "sched=0,k4_forms=0", "sched=0,reuse=0"]
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("options", FORMS)
 @pytest.mark.parametrize("n,hbw,maxdrift", [(140, 10, 0), (42, 60, 0), (84, 10, 3)])
-def test_soak(n, hbw, maxdrift):
+def test_soak(n, hbw, maxdrift, options):
+    env = dict(os.environ)
+    env["UWSPR_OPTIONS"] = options            # the one variable the library reads (uwspr_ctx_create)
+    if not options:
+        del env["UWSPR_OPTIONS"]
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_parity.py"), str(n), str(hbw),
                         str(maxdrift)],
-                       capture_output=True, text=True, timeout=600)
+                       capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "mismatches: 0" in r.stdout
+    assert ("options: %s" % (options or "(default)")) in r.stdout
 
 
 @pytest.mark.gpu

@@ -31,6 +31,9 @@ def main():
     frames = np.concatenate(parts)[:n]
     per = 4
     ctx = G.Context(halfbandwidth=hbw, maxdrift=maxdrift)
+    print("options: %s -> sched %d, stage_kernels %d, k4_forms %d, reuse %d"
+          % (os.environ.get("UWSPR_OPTIONS") or "(default)", ctx.get_option("sched"), ctx.get_option("stage_kernels"),
+             ctx.get_option("k4_forms"), ctx.get_option("reuse")))
     t0 = time.time()
     cands, out = ctx.pipeline_batch(frames, max_per_frame=per)
     tg = time.time() - t0
@@ -59,14 +62,8 @@ def main():
                 msgs.append((b, j, "slm"))
             if j < per:
                 d = O.demod_candidate(e, 1500, frames[b])
-                o = out[b, j]
-                if int(o["worth_a_try"]) != d["worth_a_try"] or int(o["shift1"]) != d["shift1"]:
-                    msgs.append((b, j, "sched", int(o["shift1"]), d["shift1"]))
-                for k in ("f1", "drift1", "sync1"):
-                    if np.float32(o[k]).tobytes() != np.float32(d[k]).tobytes():
-                        msgs.append((b, j, k, float(o[k]), float(d[k])))
-                if d["worth_a_try"] and not (o["symbols"] == d["symbols"]).all():
-                    msgs.append((b, j, "symbols", int((o["symbols"] != d["symbols"]).sum())))
+                for k in O.record_diff(out[b, j], d):
+                    msgs.append((b, j, k))
         return msgs
 
     t0 = time.time()
