@@ -7,9 +7,14 @@
  * lib/metric_tables.c) and lib/helpers.cc.  oracle/Makefile compiles those
  * files WHERE THEY LIE under /root/reference and links them with this shim
  * into oracle/_ref/libuwspr_ref.so.  Nothing of the reference is copied into
- * this repository; the .so is git-ignored AND gpurun-ignored: objects built from
- * the reference never leave this container; GPU-side tests read the
- * committed fixtures under tests/golden/ that were generated through it.
+ * this repository: the .so is git-ignored (it stays out of history).  It is NOT
+ * gpurun-ignored: like the product's own built libraries it travels with the
+ * tree to the GPU box, as the build rules of this project prescribe for
+ * oracle/_ref, so the live pin tests (tests/test_oracle_pins.py,
+ * tests/test_host_tail.py) run wherever the file is; where it is absent they
+ * skip and the committed fixtures under tests/golden/ that were generated
+ * through it (fano_ref.npz, slm_table_ref.npy) carry the same pins.  No
+ * reference SOURCE travels or is committed.
  *
  * lib/FDR_impl.cc and lib/sync_and_demodulate_impl.cc are NOT buildable here
  * (they need gnuradio/pmt/boost/fftw3/volk headers and libraries that this

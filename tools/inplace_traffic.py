@@ -5,7 +5,7 @@ samples) -- the workload of one measurement pass.  Run under rocprofv3:
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -- python3 tools/inplace_traffic.py cut|view [steps]
 
-and summarise with tools/inplace_traffic_summary.py.  The stream: noise at -20 dB with a transmission
+and sum FETCH_SIZE per kernel from the counter CSV (profiles/r03_inplace_traffic.txt is such a summary).  The stream: noise at -20 dB with a transmission
 starting every 45000 samples (every window sees one; one window in 13 sees it inside the search range).
 """
 import os, sys
