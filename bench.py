@@ -203,6 +203,10 @@ def parse_args():
                     help="seconds the library's RCCL communicator + its first gather may take before the rank exits 3")
     ap.add_argument("--trial-steps", type=int, default=100,
                     help="steps per region of the (schedule form, streams) trial: max(this, --steps), whatever --steps is")
+    ap.add_argument("--configs4-seeds", type=int, default=-1,
+                    help="noisy copies per SNR of the configs[4] leg (recording + AWGN, end to end incl. host Fano), sharded "
+                         "round-robin over the ranks; 0 skips it; default: 64 unless --no-host-legs / --total-frames "
+                         "(and, at one rank, --no-cpu) is given")
     ap.add_argument("--streams", type=int, default=0,
                     help="HIP streams (each with its own context and scratch) the steps rotate over; 0 = per --sched trial")
     return ap.parse_args()
@@ -275,6 +279,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
         world = dist.get_world_size()          # the ranks the collective library actually sees
+
+    # one process per GPU: the ranks of this node share the host's CPUs -- the Fano pool of every rank is sized by its
+    # share (uwspr_host_set_ranks), not by the whole host (configs[4] is host-bound)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world > 1:
+        G.host_set_ranks(local_world)
 
     strong = args.total_frames > 0
     B = D.local_count(args.total_frames, rank, world) if strong else args.frames
@@ -960,23 +970,70 @@ def main():
         sweep["grid_equals_flat_bitwise"] = bool(torch.equal(grid_sync, sync_t))
         result["sweep"] = sweep
 
-    # ---- BASELINE configs[4] on this one GPU: the reference's recording + AWGN at -20 .. -30 dB, end to end (host audio
-    # -> K0 = the flowgraph's front-end chain -> FDR -> S0..S5 -> records to the host -> Fano + unpack), decoded fraction
-    # and frames/s, the CPU path (oracle search + the same host tail, no front-end) beside it on a bounded sample
-    if rank == 0 and world == 1 and not args.no_cpu and not args.no_host_legs and not strong:
+    # ---- BASELINE configs[4]: the reference's recording + AWGN at -20 .. -30 dB, end to end (host audio -> K0 = the
+    # flowgraph's front-end chain -> FDR -> S0..S5 -> records to the host -> Fano + unpack), decoded fraction and frames/s.
+    # N = 1: the CPU path (oracle search + the same host tail, no front-end) beside it on a bounded sample.  N > 1: the
+    # noisy copies of every SNR are sharded round-robin over the ranks (copy s on rank s mod N), every rank decodes its
+    # shard on ITS share of the host's CPUs (uwspr_host_set_ranks), and the counts are added up: SUM of frames / decodes,
+    # MAX of the ranks' times -- no data-path exchange, three small all-reduces at the end.
+    c4_seeds = args.configs4_seeds
+    if c4_seeds < 0:
+        c4_seeds = 64 if (not args.no_host_legs and not strong and (world > 1 or not args.no_cpu)) else 0
+    if c4_seeds > 0:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import snr_sweep
-        sw = snr_sweep.run(seeds=64, cpu_seeds=8, quiet=True)
-        result["configs4_n1"] = {
-            "what": "BASELINE configs[4] at N = 1: examples/150613_1920.wav (tests/golden/150613_1920_int16.npz) + AWGN, "
-                    "64 noisy copies per SNR handed over as HOST audio (5.76 MB each, PCIe inclusive), up to 4 candidates per "
-                    "frame through the schedule, Fano + unpack on the host pool; `gpu_lazy` = uwspr_set_tries(1) + "
-                    "uwspr_demod_resume (the reference's early exit); CPU = oracle FDR + schedule + the same host tail on the "
-                    "first 8 frames of each SNR, threads as stated, no front-end; never `value`",
-            "native_snr_db": sw["native_snr_db"], "front_end": sw["front_end"],
-            "rows": [{k: r[k] for k in ("snr_db", "frames", "decoded", "other_decodes", "gpu_equals_cpu", "gpu_frames_per_s",
-                                         "gpu_lazy_frames_per_s", "cpu_frames_per_s", "cpu_frames", "cpu_threads",
-                                         "lazy_records_resumed")} for r in sw["rows"]]}
+        sw = None
+        c4_err = None
+        try:
+            import snr_sweep
+            sw = snr_sweep.run(seeds=c4_seeds, cpu_seeds=(8 if world == 1 and not args.no_cpu else 0), quiet=True,
+                               rank=rank, world=world)
+        except Exception as e:                     # noqa: BLE001 -- every rank still enters the reductions below
+            c4_err = repr(e)
+        nsn = 6
+        cnt = np.zeros((nsn, 4), np.float64)       # frames, decoded, other decodes, lazy records resumed
+        tim = np.zeros((nsn, 2), np.float64)       # eager seconds, lazy seconds
+        okf = np.array([0.0 if c4_err else 1.0] + [1.0] * nsn)
+        if sw is not None:
+            for i, r in enumerate(sw["rows"]):
+                cnt[i] = (r["frames"], r["decoded"], r["other_decodes"], r["lazy_records_resumed"])
+                tim[i] = (r["gpu_s"], r["gpu_lazy_s"])
+                okf[1 + i] = 1.0 if r["gpu_equals_cpu"] else 0.0
+        if world > 1:
+            rdev = "cpu" if backend == "gloo" else dev
+            tc_, tt_, to_ = (torch.from_numpy(v).to(rdev) for v in (cnt, tim, okf))
+            dist.all_reduce(tc_, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tt_, op=dist.ReduceOp.MAX)
+            dist.all_reduce(to_, op=dist.ReduceOp.MIN)
+            cnt, tim, okf = tc_.cpu().numpy(), tt_.cpu().numpy(), to_.cpu().numpy()
+        if rank == 0:
+            if okf[0] == 0.0 or sw is None:
+                result["configs4_n1" if world == 1 else "configs4"] = {"error": c4_err or "failed on another rank"}
+            elif world == 1:
+                result["configs4_n1"] = {
+                    "what": "BASELINE configs[4] at N = 1: examples/150613_1920.wav (tests/golden/150613_1920_int16.npz) + AWGN, "
+                            "%d noisy copies per SNR handed over as HOST audio (5.76 MB each, PCIe inclusive), up to 4 candidates per "
+                            "frame through the schedule, Fano + unpack on the host pool; `gpu_lazy` = uwspr_set_tries(1) + "
+                            "uwspr_demod_resume (the reference's early exit); CPU = oracle FDR + schedule + the same host tail on the "
+                            "first 8 frames of each SNR, threads as stated, no front-end; never `value`" % c4_seeds,
+                    "native_snr_db": sw["native_snr_db"], "front_end": sw["front_end"], "host_threads": sw["host_threads"],
+                    "rows": [{k: r[k] for k in ("snr_db", "frames", "decoded", "other_decodes", "gpu_equals_cpu", "gpu_frames_per_s",
+                                                 "gpu_lazy_frames_per_s", "cpu_frames_per_s", "cpu_frames", "cpu_threads",
+                                                 "lazy_records_resumed")} for r in sw["rows"]]}
+            else:
+                result["configs4"] = {
+                    "what": "BASELINE configs[4] over %d ranks: examples/150613_1920.wav + AWGN, %d noisy copies per SNR sharded "
+                            "round-robin (copy s on rank s mod %d, its noise a function of s), each rank: HOST audio in (PCIe "
+                            "inclusive), K0 front-end, FDR, S0..S5 for up to 4 candidates per frame, Fano + unpack on ITS share "
+                            "of the host's CPUs; frames / decodes summed over the ranks, seconds = the slowest rank's; "
+                            "`gpu_equals_lazy` = eager and lazy (uwspr_set_tries(1) + uwspr_demod_resume) decode sets equal "
+                            "on every rank; never `value`" % (world, c4_seeds, world),
+                    "ranks": world, "ranks_on_this_host": local_world, "host_threads_per_rank": sw["host_threads"],
+                    "native_snr_db": sw["native_snr_db"], "front_end": sw["front_end"],
+                    "rows": [{"snr_db": snr_sweep.SNRS[i], "frames": int(cnt[i, 0]), "decoded": int(cnt[i, 1]),
+                              "other_decodes": int(cnt[i, 2]), "lazy_records_resumed": int(cnt[i, 3]),
+                              "gpu_equals_lazy": bool(okf[1 + i] == 1.0),
+                              "gpu_frames_per_s": cnt[i, 0] / max(tim[i, 0], 1e-9),
+                              "gpu_lazy_frames_per_s": cnt[i, 0] / max(tim[i, 1], 1e-9)} for i in range(nsn)]}
     if rank == 0:
         result["parity_spot_check"] = parity_spot_check(spot_snap, D, N, "fused" if fused else "staged") if spot_snap else None
         result["cpu_baseline"] = cpu_baseline(frames_cpu[:256]) if frames_cpu is not None else None

@@ -12,7 +12,7 @@ The directory name has a hyphen; import it as `gr_uwspr_amd` (root shim).
 """
 from . import native  # noqa: F401
 from .native import UwsprError, build  # noqa: F401
-from .context import (Context, FrameView, Pipe, host_threads, deinterleave, fano_decode, fano_encode, decode_candidate, decode_batch,  # noqa: F401
+from .context import (Context, FrameView, Pipe, host_threads, host_set_ranks, deinterleave, fano_decode, fano_encode, decode_candidate, decode_batch,  # noqa: F401
                       unpack_message, c2_read, frontend_design, FRONTEND_GRC, FRONTEND_COMPACT, host_alloc, host_free)
 from . import synth  # noqa: F401
 from .sweep import sweep_grid, sweep_grid_uniform  # noqa: F401

@@ -489,6 +489,14 @@ def host_threads():
     return int(N.lib().uwspr_host_threads())
 
 
+def host_set_ranks(ranks):
+    """The `ranks` processes of a job that share this host (LOCAL_WORLD_SIZE) share its CPUs: host_threads() and the
+    process-wide Fano pool become that share.  Before the first decode_batch / Pipe of the process."""
+    rc = N.lib().uwspr_host_set_ranks(int(ranks))
+    if rc != 0:
+        raise N.UwsprError(rc, "uwspr_host_set_ranks(%d): %s" % (ranks, "the host pool already exists" if rc == -3 else "ranks < 1"))
+
+
 def decode_batch(demod_recs, nthreads=0):
     """demod_recs: DEMOD_DTYPE array (any shape). -> (messages [n,7] int8, idt [n] int32,
     decoded [n] bool), record order kept; Fano runs on `nthreads` host threads."""

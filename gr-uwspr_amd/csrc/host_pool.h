@@ -15,7 +15,8 @@
 
 namespace uwspr {
 
-int host_cpu_share();   // hardware threads capped by affinity and by the cgroup CPU quota
+int host_cpu_share();   // hardware threads capped by affinity and by the cgroup CPU quota, divided by the ranks sharing the host
+int host_set_ranks(int ranks);   // uwspr_host_set_ranks
 
 class host_pool {
  public:

@@ -221,6 +221,9 @@ namespace uwspr {
 // The CPUs this process may actually keep busy: hardware threads, capped by the scheduler affinity
 // mask and by the cgroup CPU quota (a container that sees 256 hardware threads may own 16 of them;
 // more runnable threads than that only get the whole group throttled).
+static std::atomic<int> g_ranks_on_host{1};     // uwspr_host_set_ranks: processes of the job that share this host's CPUs
+static std::atomic<bool> g_pool_made{false};
+
 int host_cpu_share() {
   int n = (int)std::thread::hardware_concurrency();
   if (n < 1) n = 1;
@@ -242,6 +245,8 @@ int host_cpu_share() {
     const int c = (int)((quota + period - 1) / period);
     if (c >= 1 && c < n) n = c;
   }
+  const int ranks = g_ranks_on_host.load(std::memory_order_relaxed);
+  if (ranks > 1) n = n / ranks > 1 ? n / ranks : 1;
   return n;
 }
 
@@ -349,8 +354,16 @@ void host_pool::run(int n, int max_threads, const std::function<void(int)> &fn) 
 }
 
 host_pool &host_pool::shared() {
+  g_pool_made.store(true);     // (before the pool is sized: a concurrent uwspr_host_set_ranks is refused, not half applied)
   static host_pool p(0);
   return p;
+}
+
+int host_set_ranks(int ranks) {
+  if (ranks < 1) return UWSPR_ERR_ARG;
+  if (g_pool_made.load()) return UWSPR_ERR_UNSUPPORTED;
+  g_ranks_on_host.store(ranks);
+  return UWSPR_OK;
 }
 
 }  // namespace uwspr
@@ -359,6 +372,7 @@ host_pool &host_pool::shared() {
 // by the process-wide persistent pool (no thread is created or joined per call), indices handed out
 // by one counter; record i's result does not depend on the thread count.
 extern "C" int uwspr_host_threads(void) { return uwspr::host_cpu_share(); }
+extern "C" int uwspr_host_set_ranks(int ranks) { return uwspr::host_set_ranks(ranks); }
 
 extern "C" int uwspr_decode_batch(const uwspr_demod_out *d, int n, int nthreads, int8_t *messages,
                                   int32_t *idt_used, uint8_t *decoded) {

@@ -235,7 +235,7 @@ ABI_SYMBOLS = [
     "uwspr_fdr_read_spectrum", "uwspr_fdr_keep_syncgrid", "uwspr_fdr_read_syncgrid",
     "uwspr_sync_sweep", "uwspr_sync_grid", "uwspr_sync_and_demodulate_batch", "uwspr_demod_batch",
     "uwspr_pipeline_batch", "uwspr_set_tries", "uwspr_set_option", "uwspr_get_option", "uwspr_demod_resume", "uwspr_pack_slabs", "uwspr_pipeline_slabs", "uwspr_prof_enable", "uwspr_prof_read", "uwspr_prof_intervals", "uwspr_deinterleave",
-    "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_host_threads", "uwspr_decode_batch", "uwspr_unpack_message",
+    "uwspr_fano_decode", "uwspr_fano_encode", "uwspr_decode_candidate", "uwspr_host_threads", "uwspr_host_set_ranks", "uwspr_decode_batch", "uwspr_unpack_message",
     "uwspr_c2_read",
     "uwspr_dist_unique_id", "uwspr_dist_init", "uwspr_dist_gather", "uwspr_dist_finalize",
     "uwspr_pipe_open", "uwspr_pipe_close", "uwspr_pipe_last_error", "uwspr_pipe_acquire", "uwspr_pipe_commit",
@@ -321,6 +321,7 @@ def lib():
     L.uwspr_decode_batch.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
     L.uwspr_decode_batch.restype = C.c_int
     L.uwspr_host_threads.argtypes = []
+    L.uwspr_host_set_ranks.argtypes = [ip]
     L.uwspr_unpack_message.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.uwspr_c2_read.argtypes = [C.c_char_p, vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.uwspr_dist_unique_id.argtypes = [vp]

@@ -28,11 +28,12 @@
 extern "C" {
 #endif
 
-#define UWSPR_ABI_VERSION 4   /* 2: frame stride, in-place stream views, uwspr_pipe_*, uwspr_dist_*, uwspr_host_threads;
+#define UWSPR_ABI_VERSION 5   /* 2: frame stride, in-place stream views, uwspr_pipe_*, uwspr_dist_*, uwspr_host_threads;
                                  3: uwspr_set_option / uwspr_get_option, uwspr_pipe_set_option, uwspr_pipe_inject_failure,
                                     uwspr_pipe_opts.spare_after_us (was reserved);
                                  4: option "frontend" (the flowgraph's GNU Radio chain is the default front-end),
-                                    uwspr_frontend_design replaces uwspr_frontend_taps */
+                                    uwspr_frontend_design replaces uwspr_frontend_taps;
+                                 5: uwspr_host_set_ranks (the host's CPU share divided between the ranks of a node) */
 
 typedef enum {
   UWSPR_OK = 0,
@@ -481,6 +482,13 @@ int uwspr_decode_candidate(const uwspr_demod_out *d, int8_t *message7,
 /* CPUs this process may keep busy: hardware threads capped by the affinity mask and the cgroup CPU
  * quota (what "one per hardware thread" means below). */
 int uwspr_host_threads(void);
+/* One process per GPU: the `ranks` processes of a job that share this host (the launcher's LOCAL_WORLD_SIZE) share its
+ * CPUs too.  After uwspr_host_set_ranks(n), uwspr_host_threads() is the share above divided by n (at least 1), and that
+ * is what the process-wide host pool -- uwspr_decode_batch, the Fano stage of uwspr_pipe_* -- is sized by: eight ranks
+ * decode on eight eighths of the host, not on eight full pools (BASELINE configs[4] is host-bound: Fano time-outs at low
+ * SNR).  Call it before the first uwspr_decode_batch / uwspr_pipe_open of the process: once the pool exists its size is
+ * fixed and the call returns UWSPR_ERR_UNSUPPORTED (nothing changes).  ranks < 1: UWSPR_ERR_ARG. */
+int uwspr_host_set_ranks(int ranks);
 /* The same for n records on `nthreads` host threads (<= 0: one per hardware
  * thread): the per-candidate loop of cc:389 with its Fano calls spread over the
  * host cores.  messages [n][7] (zero when not decoded), idt_used [n] or NULL,

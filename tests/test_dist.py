@@ -153,8 +153,8 @@ def test_bench_two_rank_rehearsal_gathers_the_one_rank_slabs():
     import torch
     if torch.cuda.device_count() != 1:
         pytest.skip("the rehearsal shares ONE device between the ranks")
-    one = _bench_line(["--gpus", "1"])
-    two = _bench_line(["--gpus", "2", "--rehearsal"])
+    one = _bench_line(["--gpus", "1", "--configs4-seeds", "4"])
+    two = _bench_line(["--gpus", "2", "--rehearsal", "--configs4-seeds", "4"])
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert one["config"]["gather"] == "none (one rank)"
     assert two["config"]["gather"] == "torch.distributed (gloo)"
@@ -166,6 +166,14 @@ def test_bench_two_rank_rehearsal_gathers_the_one_rank_slabs():
     sha = one["config"]["gathered_slabs_sha256"]
     assert sha and len(sha) == 64
     assert two["config"]["gathered_slabs_sha256"] == sha
+    # BASELINE configs[4] with N > 1: the noisy copies of every SNR sharded round-robin, each rank on its half of the
+    # host's CPUs, counts added up -- the same decodes as the one-rank sweep over the same copies
+    c1, c2 = one["configs4_n1"], two["configs4"]
+    assert c2["ranks"] == 2 and c2["ranks_on_this_host"] == 2
+    assert c2["host_threads_per_rank"] == max(1, c1["host_threads"] // 2)
+    assert [(r["snr_db"], r["frames"], r["decoded"], r["other_decodes"]) for r in c2["rows"]] == \
+           [(r["snr_db"], r["frames"], r["decoded"], r["other_decodes"]) for r in c1["rows"]]
+    assert all(r["frames"] == 4 and r["gpu_equals_lazy"] for r in c2["rows"]) and c2["rows"][0]["decoded"] == 4
     # three ranks: 50 frames = 17 + 17 + 16, the last shard padded to 17 rows that the order restore drops
     three = _bench_line(["--gpus", "3", "--rehearsal"])
     assert three["n_gpus"] == 3 and three["config"]["frames_per_gpu"] == 17
@@ -184,3 +192,84 @@ def test_bench_two_rank_rehearsal_gathers_the_one_rank_slabs():
                         "--no-cpu", "--no-sweep", "--no-lazy", "--no-host-legs"], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=300, cwd=ROOT)
     assert r.returncode == 2 and b"--rehearsal" in r.stderr
+
+
+# ---- uwspr_dist_gather with world > 1 on ONE GPU: a test double of librccl (tests/host/fake_rccl.cc) ----------------
+FAKE_DIR = os.path.join(ROOT, "tests", "host", "_fake_rccl")
+
+
+@pytest.fixture(scope="module")
+def fake_rccl():
+    """librccl.so.1 (the eight entry points csrc/dist.hip resolves, over UNIX sockets + hipMemcpy) and the C-ABI worker,
+    built with hipcc where the test runs.  The worker has no PyTorch in its process, so the library's
+    dlopen("librccl.so.1") finds the double first on LD_LIBRARY_PATH."""
+    import subprocess
+    import gr_uwspr_amd as G
+    G.native.build()
+    os.makedirs(FAKE_DIR, exist_ok=True)
+    hipcc = "/opt/rocm/bin/hipcc"
+    lib = os.path.join(FAKE_DIR, "librccl.so.1")
+    exe = os.path.join(FAKE_DIR, "dist_worker")
+    hsrc = os.path.join(ROOT, "tests", "host")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(os.path.join(hsrc, "fake_rccl.cc")):
+        subprocess.run([hipcc, "-O1", "-shared", "-fPIC", "-o", lib, os.path.join(hsrc, "fake_rccl.cc")], check=True)
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(os.path.join(hsrc, "dist_worker.cc")),
+                                                              os.path.getmtime(G.native.LIBPATH)):
+        subprocess.run([hipcc, "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(hsrc, "dist_worker.cc"), "-o", exe,
+                        "-L" + G.native.LIBDIR, "-luwspr_hip", "-Wl,-rpath," + G.native.LIBDIR], check=True)
+    return exe
+
+
+def _run_world(exe, world, root, rows, mode, tmp_path, timeout_s=5):
+    import subprocess
+    import time
+    tag = "w%d_r%d_%s" % (world, root, mode)
+    env = dict(os.environ, LD_LIBRARY_PATH=FAKE_DIR + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""),
+               FAKE_RCCL_DIR=str(tmp_path), FAKE_RCCL_LOG=str(tmp_path / ("ops_" + tag)), FAKE_RCCL_TIMEOUT_S=str(timeout_s))
+    env.pop("UWSPR_OPTIONS", None)
+    uidfile = str(tmp_path / ("uid_" + tag))
+    t0 = time.time()
+    procs = [subprocess.Popen([exe, str(r), str(world), str(root), str(rows), uidfile, mode], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=120)
+        outs.append((p.returncode, o, e))
+    ops = []
+    for r in range(world):
+        path = "%s.%d" % (env["FAKE_RCCL_LOG"], r)
+        ops.append([ln.split() for ln in open(path).read().splitlines()] if os.path.exists(path) else [])
+    return outs, ops, time.time() - t0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,root,rows", [(2, 0, 25), (2, 1, 25), (3, 0, 17), (3, 2, 17), (4, 1, 64)])
+def test_dist_gather_between_processes(fake_rccl, tmp_path, world, root, rows):
+    """uwspr_dist_unique_id / init / gather / finalize between `world` processes sharing the one GPU (rows = a shard of
+    configs[3] in small: 50 frames over 2 ranks, over 3 ranks padded to 17 rows): the root -- also a root that is not rank 0
+    -- holds rank p's bytes at recv + p * bytes, its own shard included (the self copy); every other rank sends once to the
+    root and receives nothing; the root posts world - 1 receives and sends nothing; the communicator serves a second
+    gather; a root out of range and a root without a receive buffer are argument errors."""
+    outs, ops, _ = _run_world(fake_rccl, world, root, rows, "ok", tmp_path)
+    for r, (rc, o, e) in enumerate(outs):
+        assert rc == 0 and ("GATHER_OK rank %d of %d root %d rows %d" % (r, world, root, rows)) in o, (r, rc, o, e[-800:])
+    nbytes = str(rows * 416)
+    for r in range(world):
+        if r == root:
+            assert sorted(ops[r]) == sorted([["recv", str(p), nbytes] for p in range(world) if p != root] * 2), ops[r]
+        else:
+            assert ops[r] == [["send", str(root), nbytes]] * 2, ops[r]
+
+
+@pytest.mark.gpu
+def test_dist_gather_reports_a_missing_peer_as_a_status_code(fake_rccl, tmp_path):
+    """A peer that leaves after uwspr_dist_init: the root's gather comes back with UWSPR_ERR_HIP and the collective
+    library's message within the transport's time-out -- a status code, never exit() or an exception across the C ABI.
+    (Over real RCCL a vanished peer makes the receive WAIT; bench.py bounds that with its --comm-timeout watchdog.)"""
+    outs, ops, dt = _run_world(fake_rccl, 3, 0, 17, "exit_early", tmp_path, timeout_s=3)
+    rc, o, e = outs[0]
+    assert rc == 0 and "GATHER_STATUS -4 RCCL gather: unhandled system error" in o, (rc, o, e[-800:])
+    for r in (1, 2):
+        assert outs[r][0] == 0 and "EXIT_EARLY" in outs[r][1]
+        assert ops[r] == []
+    assert dt < 60.0

@@ -61,16 +61,21 @@ def cpu_decode(fdr, frame):
     return texts
 
 
-def run(seeds=8, cpu_seeds=None, quiet=False):
-    """The sweep; the CPU leg (and the GPU == CPU comparison) covers the first cpu_seeds frames of every SNR."""
-    cpu_seeds = seeds if cpu_seeds is None else min(cpu_seeds, seeds)
+def run(seeds=8, cpu_seeds=None, quiet=False, rank=0, world=1):
+    """The sweep; the CPU leg (and the GPU == CPU comparison) covers the first cpu_seeds frames of every SNR.
+    rank / world (bench.py --gpus N): the `seeds` noisy copies of every SNR are sharded round-robin like the frames of the
+    search path (copy s on rank s mod world, its noise a function of s: the union over the ranks is the one-rank sweep);
+    this rank's rows count ITS copies, the caller adds them up; host threads = this rank's share of the host
+    (uwspr_host_set_ranks)."""
+    mine = list(range(rank, seeds, world))
+    cpu_seeds = len(mine) if cpu_seeds is None else min(cpu_seeds, len(mine))
     say = (lambda *a: None) if quiet else print
     x = np.load(os.path.join(ROOT, "tests", "golden", "150613_1920_int16.npz"))["x"].astype(np.float32) / 32768.0
     ctx = G.Context()
     lazy = G.Context()           # the reference's own early exit: try 0 only, the rest on demand
     lazy.set_tries(1)
     O.lib(); O.pr3()
-    nw = min(16, len(os.sched_getaffinity(0)))
+    nw = max(1, min(16, G.host_threads()))       # affinity, cgroup quota and the ranks sharing the host applied
     fdrs = [O.FDR() for _ in range(nw)]
     # the recording's own SNR is a property of the recording: estimated once through the WIDE compact front-end (the
     # flowgraph's chain passes 1500 +- 10 Hz only: no noise-reference band is left beside the signal)
@@ -91,16 +96,22 @@ def run(seeds=8, cpu_seeds=None, quiet=False):
     for snr in SNRS:
         n0_target = ps / (2500.0 * 10 ** (snr / 10.0))
         sigma = np.sqrt(max(n0_target - n0, 0.0) * 12000.0)     # real AWGN at 12 kS/s: density sigma^2/12000 per Hz
-        audio = np.empty((seeds, x.size), np.float32)
-        for s in range(seeds):
+        if not mine:                                   # more ranks than copies: this rank has nothing at this SNR
+            rows.append({"snr_db": snr, "frames": 0, "decoded": 0, "other_decodes": 0, "gpu_equals_cpu": True, "gpu_s": 0.0,
+                         "gpu_lazy_s": 0.0, "lazy_records_resumed": 0, "records": 0, "cpu_s": 0.0, "cpu_frames": 0,
+                         "cpu_threads": nw, "gpu_frames_per_s": 0.0, "gpu_lazy_frames_per_s": 0.0, "cpu_frames_per_s": 0.0})
+            continue
+        audio = np.empty((len(mine), x.size), np.float32)
+        for k, s in enumerate(mine):
             rng = np.random.Generator(np.random.Philox(int(1000 * -snr) + s))
-            audio[s] = x + sigma * rng.standard_normal(x.size).astype(np.float32)
+            audio[k] = x + sigma * rng.standard_normal(x.size).astype(np.float32)
+        seeds_l = len(mine)
         t0 = time.time()
         frames = ctx.frontend(audio)
         cands, out = ctx.pipeline_batch(frames, max_per_frame=PER)
-        msg, _, okv = G.decode_batch(out, nthreads=nw)      # [seeds*PER] records, host threads
+        msg, _, okv = G.decode_batch(out, nthreads=0)      # [seeds*PER] records, host threads
         gpu_texts = []
-        for b in range(seeds):
+        for b in range(seeds_l):
             gpu_texts.append([G.unpack_message(msg[b * PER + j])[1] for j in range(min(PER, len(cands[b])))
                               if okv[b * PER + j]])
         tg = time.time() - t0
@@ -108,40 +119,42 @@ def run(seeds=8, cpu_seeds=None, quiet=False):
         t0 = time.time()
         frames_l = lazy.frontend(audio)
         cands_l, out_l = lazy.pipeline_batch(frames_l, max_per_frame=PER)
-        msg_l, _, ok_l = G.decode_batch(out_l, nthreads=nw)
+        msg_l, _, ok_l = G.decode_batch(out_l, nthreads=0)
         need = ((out_l["worth_a_try"] != 0) & ~ok_l.reshape(out_l.shape)).astype(np.uint8)
         resumed = int(need.sum())
         if resumed:
             out_r = lazy.demod_resume(frames_l, need, None, max_per_frame=PER)
             idx = np.flatnonzero(need.reshape(-1))
-            msg_r, _, ok_r = G.decode_batch(out_r.reshape(-1)[idx], nthreads=nw)
+            msg_r, _, ok_r = G.decode_batch(out_r.reshape(-1)[idx], nthreads=0)
             msg_l[idx] = msg_r
             ok_l[idx] = ok_r
         lazy_texts = []
-        for b in range(seeds):
+        for b in range(seeds_l):
             lazy_texts.append([G.unpack_message(msg_l[b * PER + j])[1] for j in range(min(PER, len(cands_l[b])))
                                if ok_l[b * PER + j]])
         tl = time.time() - t0
         t0 = time.time()
-        with ThreadPoolExecutor(nw) as ex:
-            cpu_texts = list(ex.map(lambda a: cpu_decode(fdrs[a % nw], frames[a]), range(cpu_seeds)))
-        tc = time.time() - t0
+        cpu_texts = []
+        if cpu_seeds:
+            with ThreadPoolExecutor(nw) as ex:
+                cpu_texts = list(ex.map(lambda a: cpu_decode(fdrs[a % nw], frames[a]), range(cpu_seeds)))
+        tc = max(time.time() - t0, 1e-9)
         ok = sum(WANT in t for t in gpu_texts)
         false_dec = sum(len([u for u in t if u != WANT]) for t in gpu_texts)
         same = gpu_texts[:cpu_seeds] == cpu_texts and lazy_texts[:cpu_seeds] == cpu_texts and gpu_texts == lazy_texts
-        rows.append({"snr_db": snr, "frames": seeds, "decoded": ok, "other_decodes": false_dec,
+        rows.append({"snr_db": snr, "frames": seeds_l, "decoded": ok, "other_decodes": false_dec,
                      "gpu_equals_cpu": same, "gpu_s": tg, "gpu_lazy_s": tl, "lazy_records_resumed": resumed,
                      "records": int((out_l["worth_a_try"] != 0).sum()), "cpu_s": tc, "cpu_frames": cpu_seeds,
-                     "cpu_threads": nw, "gpu_frames_per_s": seeds / tg, "gpu_lazy_frames_per_s": seeds / tl,
+                     "cpu_threads": nw, "gpu_frames_per_s": seeds_l / tg, "gpu_lazy_frames_per_s": seeds_l / tl,
                      "cpu_frames_per_s": cpu_seeds / tc})
         say("SNR %5.1f dB: %2d/%d decoded, %d other decodes, GPU==lazy==CPU %s, GPU %.1f ms eager / %.1f ms lazy "
               "(%d of %d records resumed) (host audio in, front-end + search + Fano), CPU %.1f ms on %d threads "
               "(search + Fano, no front-end)"
-              % (snr, ok, seeds, false_dec, same, 1e3 * tg, 1e3 * tl, resumed, rows[-1]["records"], 1e3 * tc, nw))
+              % (snr, ok, seeds_l, false_dec, same, 1e3 * tg, 1e3 * tl, resumed, rows[-1]["records"], 1e3 * tc, nw))
     ctx.close()
     lazy.close()
     return {"recording": "examples/150613_1920.wav", "native_snr_db": float(native), "front_end": "K0, option frontend = 0 (the flowgraph's GNU Radio chain)",
-            "candidates_per_frame": PER, "rows": rows}
+            "candidates_per_frame": PER, "host_threads": G.host_threads(), "rank": rank, "world": world, "rows": rows}
 
 
 def main():
