@@ -32,10 +32,13 @@ namespace {
 
 struct uid_t128 { char internal[128]; };
 
+struct early_msg { int src; std::vector<char> data; };
+
 struct comm {
   int rank, world;
   std::string base;
   int lfd;
+  std::vector<early_msg> early;   // messages of a LATER group that arrived while this rank was still in an earlier one
 };
 
 struct op {
@@ -123,6 +126,17 @@ int do_send(const op &o) {
 int do_recvs(comm *c, std::vector<op *> &rs) {
   const double t_end = now() + timeout_s();
   size_t done = 0;
+  // a peer may already be one gather ahead (it sends, returns, sends again while the root is still receiving the first
+  // round from a slower peer): transfers between two ranks are ordered, so such a message waits for its own group
+  for (op *r : rs)
+    for (size_t e = 0; e < c->early.size(); e++)
+      if (c->early[e].src == r->peer && c->early[e].data.size() == r->bytes) {
+        if (hipMemcpy(r->buf, c->early[e].data.data(), r->bytes, hipMemcpyHostToDevice) != hipSuccess) return kSystemError;
+        c->early.erase(c->early.begin() + (long)e);
+        r->buf = nullptr;
+        done++;
+        break;
+      }
   while (done < rs.size()) {
     struct pollfd pf = {c->lfd, POLLIN, 0};
     const double left = t_end - now();
@@ -131,14 +145,18 @@ int do_recvs(comm *c, std::vector<op *> &rs) {
     if (fd < 0) return kSystemError;
     uint64_t hdr[2];
     if (!rd(fd, hdr, sizeof(hdr), t_end)) { close(fd); return kSystemError; }
+    if (hdr[0] >= (uint64_t)c->world || hdr[1] > (1ull << 32)) { close(fd); return kInvalidArgument; }
     op *m = nullptr;
     for (op *r : rs)
       if (r->buf && r->peer == (int)hdr[0] && r->bytes == hdr[1]) { m = r; break; }
-    if (!m) { close(fd); return kInvalidArgument; }                                        // nobody asked for this
-    std::vector<char> h(m->bytes);
-    const bool ok = rd(fd, h.data(), m->bytes, t_end);
+    std::vector<char> h(hdr[1]);
+    const bool ok = rd(fd, h.data(), h.size(), t_end);
     close(fd);
     if (!ok) return kSystemError;
+    if (!m) {                                       // not of this group: the sender is a gather ahead
+      c->early.push_back(early_msg{(int)hdr[0], std::move(h)});
+      continue;
+    }
     if (hipMemcpy(m->buf, h.data(), m->bytes, hipMemcpyHostToDevice) != hipSuccess) return kSystemError;
     m->buf = nullptr;                                                                      // matched
     done++;
@@ -180,7 +198,7 @@ int ncclGetUniqueId(uid_t128 *id) {
 int ncclCommInitRank(void **out, int nranks, uid_t128 id, int rank) {
   if (!out || nranks < 1 || rank < 0 || rank >= nranks || !id.internal[0]) return kInvalidArgument;
   id.internal[127] = 0;
-  comm *c = new comm{rank, nranks, std::string(id.internal), -1};
+  comm *c = new comm{rank, nranks, std::string(id.internal), -1, {}};
   const sockaddr_un a = addr_of(c->base, rank);
   unlink(a.sun_path);
   c->lfd = socket(AF_UNIX, SOCK_STREAM, 0);
