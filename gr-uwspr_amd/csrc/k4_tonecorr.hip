@@ -697,13 +697,157 @@ __global__ __launch_bounds__(256, 4) void k4_lag0(   // 4 wavefronts per SIMD: <
   }
 }
 
+// ---- round 6 (review item 4: "take the barriers out of k4_lag0"): two experimental forms of the same walk, option
+// k4_forms bits 1 and 2, A/B in profiles/r06_k4_lag0_ab.txt.
+//   WSETS = 1: the staged rows DOUBLE-BUFFERED -- chunk c + 1 is stored into the other buffer right behind the arithmetic
+//              of chunk c: ONE workgroup barrier per chunk instead of two (34.8 + 16 KB of LDS: three workgroups per CU,
+//              which is all a 256-candidate launch brings: 2.55 per CU).
+//   WSETS = 2: the same, and the four lags of a row on TWO wavefronts per tone (lags {0, 2} and {1, 3}: both sets are
+//              busy 12 of the 14 chunks): 8 wavefronts per workgroup, twice the wavefronts per SIMD for the same
+//              arithmetic (a wavefront issues at most one instruction per 4.5 cycles: a launch of 2.5 wavefronts per
+//              SIMD cannot fill the issue slots by itself), at the price of every staged sample being read by two lanes.
+// The wrap (lag 4 = lag 0 one symbol later) and the operation order of every accumulator are the packed form's.
+template <int WSETS>
+__global__ __launch_bounds__(256 * WSETS, WSETS == 1 ? 3 : 6) void k4_lag0x(
+    const float2 *__restrict__ frames, int fstride, int np, int nframes, const dev_grp *__restrict__ grps,
+    int nslots, float *__restrict__ p_out, const float2 *__restrict__ ptab) {
+  constexpr int NT = 256 * WSETS;
+  constexpr int ROWS = 64, CH = 32, ROWDW = 2 * CH + 4, SEGS = NT / CH, NR = ROWS / SEGS, NCHUNK = 14;
+  __shared__ __align__(16) float smp[2][ROWS * ROWDW];
+  __shared__ __align__(16) float4 tab[2][4][128];   // [slot A/B][tone][step pair]: the slot's whole table
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tone = wv & 3;
+  const int wset = wv >> 2;                          // WSETS == 2: 0 = lags {0, 2}, 1 = lags {1, 3}
+  const long long total = (long long)nslots * K4L_ROWS_PER_SLOT;
+  const long long g0 = (long long)xcd_swizzle(blockIdx.x, gridDim.x) * ROWS;
+  if (g0 >= total) return;  // workgroup-uniform
+
+  const int slotA = (int)(g0 / K4L_ROWS_PER_SLOT);
+  const int rA0 = (int)(g0 - (long long)slotA * K4L_ROWS_PER_SLOT);
+  const int sb = min(ROWS, K4L_ROWS_PER_SLOT - rA0);      // rows < sb belong to slot A
+  const bool hasB = sb < ROWS && slotA + 1 < nslots;
+  const int slotB = hasB ? slotA + 1 : slotA;
+  const dev_grp A = grps[slotA], Bg = grps[slotB];
+  const int selA = (A.nvalid >> 16) & 0xff, selB = (Bg.nvalid >> 16) & 0xff;
+  const bool doA = A.frame >= 0 && A.frame < nframes && selA != 0;
+  const bool doB = hasB && Bg.frame >= 0 && Bg.frame < nframes && selB != 0;
+  if (!doA && !doB) return;  // workgroup-uniform
+
+#pragma unroll
+  for (int sl = 0; sl < 2; sl++) {
+    if (!(sl ? doB : doA)) continue;
+    const float4 *src = reinterpret_cast<const float4 *>(
+        ptab + ((size_t)(sl ? slotB : slotA) * kPtabPerSlot + ((sl ? selB : selA) - 1)) * kPtabFloat2);
+    float4 *dst = &tab[sl][0][0];
+    for (int e = tid; e < 512; e += NT) dst[e] = src[e];
+  }
+
+  const int row = lane;
+  const bool mineA = row < sb;
+  const int own_r = mineA ? rA0 + row : row - sb;       // 0..161 real symbols, 162 the virtual row
+  const bool own_do = mineA ? doA : doB;
+  const bool valid = (g0 + row < total) && (mineA || hasB) && own_do;
+
+  const int kk = tid % CH, seg = tid / CH;
+  const float2 *fbA = frames + (long long)(doA ? A.frame : 0) * fstride;
+  const float2 *fbB = frames + (long long)(doB ? Bg.frame : 0) * fstride;
+  const int nA0 = A.lag[0] + 256 * rA0, nB0 = Bg.lag[0];
+  const bool interior = doA && (nA0 > 0) && (nA0 + 256 * (sb - 1) + 32 * NCHUNK < np) &&
+                        (sb >= ROWS || (doB && (nB0 > 0) && (nB0 + 256 * (ROWS - sb - 1) + 32 * NCHUNK < np)));
+  float2 stage[NR];
+  int nrow[NR];
+  bool rowB[NR];
+#pragma unroll
+  for (int r = 0; r < NR; r++) {
+    const int rw = SEGS * r + seg;
+    rowB[r] = rw >= sb;
+    nrow[r] = (rowB[r] ? nB0 + 256 * (rw - sb) : nA0 + 256 * rw) + kk;
+  }
+  auto load_chunk = [&](int c) {
+    if (interior) {
+#pragma unroll
+      for (int r = 0; r < NR; r++) stage[r] = (rowB[r] ? fbB : fbA)[nrow[r] + CH * c];
+    } else {
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+        const int n = nrow[r] + CH * c;
+        const bool inr = (n > 0) && (n < np);      // cc:205, sample 0 excluded
+        const float2 v = (rowB[r] ? fbB : fbA)[min(max(n, 0), np - 1)];
+        stage[r] = inr ? v : make_float2(0.0f, 0.0f);
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+      *reinterpret_cast<float2 *>(&smp[buf][(SEGS * r + seg) * ROWDW + 2 * kk]) = stage[r];
+  };
+
+  float inp[4], quad[4];
+#pragma unroll
+  for (int q = 0; q < 4; q++) { inp[q] = 0.0f; quad[q] = 0.0f; }
+  const float4 *tabrow = &tab[mineA ? 0 : 1][tone][0];
+
+  // chunk 0 into buffer 0, chunk 1 on its way; from then on: arithmetic of chunk c from buffer c & 1, chunk c + 1 into the
+  // other buffer (its last readers passed the barrier that ended chunk c - 1), chunk c + 2 requested, ONE barrier
+  load_chunk(0);
+  store_chunk(0);
+  load_chunk(1);
+  __syncthreads();
+  auto phase = [&](auto mask_tag, int c0) {
+    constexpr int QM = decltype(mask_tag)::value;
+#pragma unroll 1
+    for (int c = c0; c < c0 + 2; c++) {
+      if (WSETS == 1) {
+        k4_lag0_chunk<QM, false>(&smp[c & 1][row * ROWDW], tabrow, 32 * c, inp, quad);
+      } else if (wset == 0) {            // wavefront-uniform
+        if (QM & 0x5) k4_lag0_chunk<QM & 0x5, false>(&smp[c & 1][row * ROWDW], tabrow, 32 * c, inp, quad);
+      } else {
+        if (QM & 0xa) k4_lag0_chunk<QM & 0xa, false>(&smp[c & 1][row * ROWDW], tabrow, 32 * c, inp, quad);
+      }
+      store_chunk((c + 1) & 1);
+      load_chunk(min(c + 2, NCHUNK - 1));
+      __syncthreads();
+    }
+  };
+  phase(std::integral_constant<int, 0x1>{}, 0);
+  phase(std::integral_constant<int, 0x3>{}, 2);
+  phase(std::integral_constant<int, 0x7>{}, 4);
+  phase(std::integral_constant<int, 0xf>{}, 6);
+  phase(std::integral_constant<int, 0xe>{}, 8);
+  phase(std::integral_constant<int, 0xc>{}, 10);
+  phase(std::integral_constant<int, 0x8>{}, 12);
+
+  if (valid) {
+    const int hb = mineA ? A.hyp_base : Bg.hyp_base;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (WSETS == 2 && (q & 1) != wset) continue;
+      const float pj = ieee_sqrtf(inp[q] * inp[q] + quad[q] * quad[q]);   // cc:211
+      if (own_r < UWSPR_NSYM) p_out[((long long)(hb + q) * UWSPR_NSYM + own_r) * 4 + tone] = pj;
+      // the wrap: (first lag, symbol r) is also (fifth lag, symbol r - 1)
+      if (q == 0 && own_r >= 1) p_out[((long long)(hb + 4) * UWSPR_NSYM + own_r - 1) * 4 + tone] = pj;
+    }
+  }
+}
+
 void launch_tonecorr_lag0(uwspr_ctx *c, const float *frames, int B, const dev_grp *grps, int nslots,
                           int64_t nhyps, float4 *p) {
   if (nslots <= 0) return;
   prof_scope ps(c, UWSPR_K_TONECORR, nhyps, true);
   const unsigned wgs = (unsigned)(((long long)nslots * K4L_ROWS_PER_SLOT + 63) / 64);
+  const int form = c->fast_now ? 0 : (c->opt[UWSPR_OPT_K4_FORMS] >> 1) & 3;     // bit 1: double-buffered; bit 2: + lag pairs
   if (c->fast_now)
     launch_timed(c, ps, k4_lag0<true>, dim3(wgs), dim3(256), 0, (const float2 *)frames, c->fstride, c->np, B, grps,
+                 nslots, (float *)p, (const float2 *)c->d_ptab);
+  else if (form & 2)
+    launch_timed(c, ps, k4_lag0x<2>, dim3(wgs), dim3(512), 0, (const float2 *)frames, c->fstride, c->np, B, grps,
+                 nslots, (float *)p, (const float2 *)c->d_ptab);
+  else if (form & 1)
+    launch_timed(c, ps, k4_lag0x<1>, dim3(wgs), dim3(256), 0, (const float2 *)frames, c->fstride, c->np, B, grps,
                  nslots, (float *)p, (const float2 *)c->d_ptab);
   else
     launch_timed(c, ps, k4_lag0<false>, dim3(wgs), dim3(256), 0, (const float2 *)frames, c->fstride, c->np, B, grps,

@@ -314,6 +314,8 @@ def test_schedule_forms_are_identical(G, frames, vec):
                  {"sched": 0, "stage_kernels": 1, "phasor_tables": 0},
                  {"sched": 0, "stage_kernels": 1, "k4_forms": 0},      # S5 through the LDS-ring kernel (round 4's form)
                  {"sched": 0, "stage_kernels": 1, "k4_forms": 0, "reuse": 0},
+                 {"sched": 0, "stage_kernels": 1, "k4_forms": 3},      # S0 double-buffered, one barrier per chunk (round 6)
+                 {"sched": 0, "stage_kernels": 1, "k4_forms": 5},      # S0: + its lags on two wavefronts per tone
                  {"sched": 1, "reuse": 0}):
         c = G.Context(options=opts)
         try:
