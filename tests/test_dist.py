@@ -224,7 +224,8 @@ def _run_world(exe, world, root, rows, mode, tmp_path, timeout_s=5):
     import subprocess
     import time
     tag = "w%d_r%d_%s" % (world, root, mode)
-    env = dict(os.environ, LD_LIBRARY_PATH=FAKE_DIR + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""),
+    import gr_uwspr_amd as G
+    env = dict(os.environ, LD_LIBRARY_PATH=os.pathsep.join([FAKE_DIR, G.native.LIBDIR, os.environ.get("LD_LIBRARY_PATH", "")]),
                FAKE_RCCL_DIR=str(tmp_path), FAKE_RCCL_LOG=str(tmp_path / ("ops_" + tag)), FAKE_RCCL_TIMEOUT_S=str(timeout_s))
     env.pop("UWSPR_OPTIONS", None)
     uidfile = str(tmp_path / ("uid_" + tag))
