@@ -10,3 +10,9 @@ UWSPR_OPTIONS=sched=0,k4_forms=0 python3 tools/soak_parity.py 800 10 0 135000   
 UWSPR_OPTIONS=sched=0,k4_forms=3 python3 tools/soak_parity.py 800 10 0 136000            # S0 double-buffered (round 6's experiment)
 UWSPR_OPTIONS=sched=0,k4_forms=5 python3 tools/soak_parity.py 800 10 0 137000            # S0 on two wavefronts per tone
 python3 tools/soak_parity.py 1500 10 0 138000                                            # fused (default)
+# the long leg (argument "long"): 40 000 more frames through the staged form in chunks of 5 000 (1.8 GB of host frames each)
+if [ "$1" = "long" ]; then
+  for k in 0 1 2 3 4 5 6 7; do
+    UWSPR_OPTIONS=sched=0 python3 tools/soak_parity.py 5000 10 0 $((140000 + 1000 * k))
+  done
+fi
