@@ -56,8 +56,17 @@
 
 namespace uwspr {
 
-constexpr int K6_WAVES = 16;
+// K6_SLOTS: hypothesis slots per tone.  4 = the library's form (16 wavefronts: one workgroup fills a CU).  2 = round 6's
+// EXPERIMENT build only (UWSPR_EXTRA_HIPFLAGS=-DK6_SLOTS=2, its own library file; with option sched_grid = 512): 8 wavefronts
+// per candidate, two hypotheses per loaded sample in S0-S4, two workgroups per CU -- review item 3, measured in
+// profiles/r06_k6_slots_ab.txt.  Everything the default build compiles is unchanged by the macro.
+#ifndef K6_SLOTS
+#define K6_SLOTS 4
+#endif
+static_assert(K6_SLOTS == 4 || K6_SLOTS == 2, "K6_SLOTS");
+constexpr int K6_WAVES = 4 * K6_SLOTS;
 constexpr int K6_THREADS = 64 * K6_WAVES;
+constexpr int K6_LROWS = K6_THREADS / 16;     // rows one loader round covers: 64 / 32
 
 constexpr int K6_TROWS = 54;                  // rows per row-role wavefront: 162 = 3 x 54
 constexpr int K6_MAXROWS = UWSPR_NSYM + 1;    // + the virtual row of the S0 wrap
@@ -67,6 +76,7 @@ constexpr int K6_TABSET = K6_NTAB * 4 * 512;  // floats per table set: [freq][to
 constexpr int K6_PSLAB = K6_MAXROWS * 4;      // floats per hypothesis in the p image
 constexpr int K6_FOLDH = 9;                   // hypotheses folded per round
 constexpr int K6_CMS = UWSPR_NSYM + 2;        // stride of the per-hypothesis scratch rows
+constexpr int K6_NLD = (K6_MAXROWS + K6_LROWS - 1) / K6_LROWS;   // loader rounds per chunk: 3 / 6
 
 constexpr double kTwoPiDt6 = 2.0 * 3.14159265358979323846 * (double)(float)(1.0 / 375.0);  // cc:146,188
 
@@ -135,12 +145,20 @@ template <int KIND> struct k6_geom {
   // (row, hypothesis) pairs each.  Hypotheses that are usually known (the middle one of S1/S3/S4,
   // try 0 of S5, the wrapped last lag of S0) ride on a slot as an extra.
   __host__ __device__ static constexpr uint32_t slot_mask(int s) {
+#if K6_SLOTS == 2
+    // two slots: an early and a late lag each (S0), the halves of the frequency row (S1 / S4 / S3), S5's 8 + 9
+    return KIND == K6_S0 ? (s == 0 ? 0x09u : 0x16u)
+         : KIND == K6_S2 ? (s == 0 ? 0x1u : 0x2u)
+         : KIND == K6_S5 ? (s == 0 ? 0x0cccdu : 0x13332u)
+         : (s == 0 ? 0x07u : 0x18u);
+#endif
     return KIND == K6_S0 ? (s == 3 ? 0x18u : 1u << s)
          : KIND == K6_S2 ? (s == 0 ? 0x1u : s == 1 ? 0x2u : s == 2 ? 0x3u : 0u)
          : KIND == K6_S5 ? (s == 0 ? 0x08485u : s == 1 ? 0x03030u : s == 2 ? 0x04848u : 0x10302u)
          : (s == 0 ? 0x05u : s == 1 ? 0x02u : s == 2 ? 0x08u : 0x10u);
   }
   __host__ __device__ static constexpr uint32_t row_mask(int s, int h) {
+    if (K6_SLOTS == 2) return 0x7u;
     return KIND == K6_S2 ? (s == 2 ? 0x4u : 0x3u) : 0x7u;
   }
   __host__ __device__ static constexpr int dk8(int h) {
@@ -184,19 +202,19 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int np, int 
   const int lr = tid >> 4, lj = tid & 15;
   const int sbase = lr * K6_ROWDW + 2 * lj;
   const bool interior = (L0 > 0) && (L0 + 256 * (nrows - 1) + 16 * nchunks < np);   // workgroup-uniform
-  float2 greg[3];
+  float2 greg[K6_NLD];
   auto gload = [&](int c) {
     if (interior) {
 #pragma unroll
-      for (int n = 0; n < 3; n++) {
-        const int r = min(lr + 64 * n, nrows - 1);
+      for (int n = 0; n < K6_NLD; n++) {
+        const int r = min(lr + K6_LROWS * n, nrows - 1);
         const v2f v = fbg[L0 + 256 * r + lj + 16 * c];
         greg[n] = make_float2(v.x, v.y);
       }
     } else {
 #pragma unroll
-      for (int n = 0; n < 3; n++) {
-        const int r = min(lr + 64 * n, nrows - 1);
+      for (int n = 0; n < K6_NLD; n++) {
+        const int r = min(lr + K6_LROWS * n, nrows - 1);
         const int ns = L0 + 256 * r + lj + 16 * c;
         const bool inr = (ns > 0) && (ns < np);                 // cc:205, sample 0 excluded
         const v2f v = fbg[min(max(ns, 0), np - 1)];
@@ -206,9 +224,9 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int np, int 
   };
   auto gstore = [&](int buf) {
 #pragma unroll
-    for (int n = 0; n < 3; n++)
-      if (lr + 64 * n < nrows)
-        *(lds_f2 *)(&stage[buf * K6_MAXROWS * K6_ROWDW + sbase + 64 * n * K6_ROWDW]) = v2f{greg[n].x, greg[n].y};
+    for (int n = 0; n < K6_NLD; n++)
+      if (lr + K6_LROWS * n < nrows)
+        *(lds_f2 *)(&stage[buf * K6_MAXROWS * K6_ROWDW + sbase + K6_LROWS * n * K6_ROWDW]) = v2f{greg[n].x, greg[n].y};
   };
 
   // ---- the walk of one hypothesis slot: three rows per lane, the hypotheses of slot_mask(SLOT)
@@ -258,7 +276,7 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int np, int 
     const K6_CONST float *tabw = (const K6_CONST float *)tabset + tone * 512 + (SHARED ? tq0 * 2048 : 0);
     const uint32_t wmask = mask & SM;
     // rows this slot reads at all (S2's third slot walks only the last row of each lane)
-    constexpr uint32_t ROWS = KIND == K6_S2 ? (SLOT == 2 ? 0x4u : SLOT == 3 ? 0u : 0x3u) : 0x7u;
+    constexpr uint32_t ROWS = (KIND == K6_S2 && K6_SLOTS == 4) ? (SLOT == 2 ? 0x4u : SLOT == 3 ? 0u : 0x3u) : 0x7u;
 
     for (int c = 0; c < nchunks; c++) {
       gload(min(c + 1, nchunks - 1));           // in flight during the arithmetic
@@ -397,6 +415,12 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int np, int 
   __syncthreads();
   // every slot executes the same number of barriers (one per chunk)
   bool paired = false;
+#if K6_SLOTS == 2
+  // (the experiment build walks S2's two tries one per slot: the mirrored pair walk wants 163 pair-rows on three slots)
+  (void)paired; (void)walk_pair;
+  if ((wv >> 2) == 0) walk(std::integral_constant<int, 0>{});
+  else walk(std::integral_constant<int, 1>{});
+#else
   if (KIND == K6_S2) paired = uni((m_type == UWSPR_LINEAR && drp == -drm && mask == 0x3u) ? 1 : 0) != 0;
   if (KIND == K6_S2 && paired) {
     switch (wv >> 2) {
@@ -413,6 +437,7 @@ __device__ __noinline__ void k6_pass(const float2 *__restrict__ fb, int np, int 
       default: walk(std::integral_constant<int, 3>{}); break;
     }
   }
+#endif
   __syncthreads();
 }
 
@@ -535,7 +560,11 @@ __device__ __forceinline__ const float *launder(const float *p) {
   return p;
 }
 
+#if K6_SLOTS == 2
+__global__ __launch_bounds__(K6_THREADS, 4) void k6_sched(k6_args a) {     // 8 wavefronts at <= 128 VGPRs: two workgroups per CU
+#else
 __global__ __launch_bounds__(K6_THREADS) void k6_sched(k6_args a) {
+#endif
   __shared__ __align__(16) float stage[2 * K6_MAXROWS * K6_ROWDW];   // staging, then p[h][163][4]
   __shared__ __align__(16) float pw[UWSPR_NSYM * 4];                 // the current winner's magnitudes
   __shared__ k6_fold_lds F;
