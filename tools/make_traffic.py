@@ -60,7 +60,15 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import gr_uwspr_amd as G
-    out["library_sources_sha256"] = G.native.source_digest()   # bench.py refuses the figures for any other build
+    # the digest of the sources the counters were TAKEN on (tools/run_profiles.sh writes it on the GPU box); a profile
+    # directory of an earlier round has none: then the tree's own, as before.  bench.py refuses the figures for any other build
+    dpath = os.path.join(sys.argv[1], "library_sources_sha256.txt")
+    here = G.native.source_digest()
+    taken = open(dpath).read().strip() if os.path.exists(dpath) else here
+    if taken != here:
+        print("WARNING: the counters were taken on sources %s..., this tree is %s...: bench.py will report them stale"
+              % (taken[:12], here[:12]), file=sys.stderr)
+    out["library_sources_sha256"] = taken
     json.dump(out, open(os.path.join(root, "profiles", "k4_traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 

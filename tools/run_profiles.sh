@@ -6,6 +6,7 @@ TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+python3 -c "import gr_uwspr_amd as G; print(G.native.source_digest())" > $OUT/library_sources_sha256.txt   # what the counters belong to
 hipcc --offload-arch=gfx950 -O2 tools/fetch_calib.hip -o /tmp/fetch_calib 2>/dev/null
 for form in fused staged; do
   B="python3 bench.py --no-cpu --no-sweep --no-lazy --no-host-legs --sched $form --streams 1 --repeats 1"
