@@ -220,7 +220,7 @@ def fake_rccl():
     return exe
 
 
-def _run_world(exe, world, root, rows, mode, tmp_path, timeout_s=5):
+def _run_world(exe, world, root, rows, mode, tmp_path, timeout_s=60):
     import subprocess
     import time
     tag = "w%d_r%d_%s" % (world, root, mode)
@@ -234,7 +234,7 @@ def _run_world(exe, world, root, rows, mode, tmp_path, timeout_s=5):
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
     outs = []
     for p in procs:
-        o, e = p.communicate(timeout=120)
+        o, e = p.communicate(timeout=240)
         outs.append((p.returncode, o, e))
     ops = []
     for r in range(world):
