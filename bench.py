@@ -664,13 +664,14 @@ def main():
     if world > 1:
         dist.barrier()
 
-    frames_cpu = batches[0].cpu().numpy() if (rank == 0 and world == 1 and not args.no_host_legs) else None
+    # a host copy of one batch: for the host-pointer legs and for cpu_baseline (which --no-host-legs alone does not switch off)
+    frames_cpu = batches[0].cpu().numpy() if (rank == 0 and world == 1 and not (args.no_host_legs and args.no_cpu)) else None
     # the same batch handed over as HOST buffers (what a GNU Radio block does per PDU batch):
     # H2D of the frames + D2H of every result, PCIe inclusive; never `value`
     host_rate = None
     host_pinned_rate = None
     host_legs_detail = None
-    if frames_cpu is not None:
+    if frames_cpu is not None and not args.no_host_legs:
         def host_leg(buf, calls=10):
             ctx.pipeline_batch(buf, max_per_frame=1)          # untimed: allocations, first touch
             ts = []
