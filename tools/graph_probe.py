@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """(GPU box) Does a hipGraph of the step help?  The timed configuration of bench.py (staged form, three lanes, 256-frame
 batches rotating over five) with every (lane, batch) step captured ONCE into a graph (stream capture of the library's
-own launches through torch.cuda.graph) and replayed, against the same steps launched eagerly.  usage: graph_probe.py [steps]"""
+own launches through torch.cuda.graph) and replayed, against the same steps launched eagerly.  usage: graph_probe.py [steps] [lanes]"""
 import os
 import sys
 import time
@@ -15,7 +15,8 @@ import gr_uwspr_amd as G  # noqa: E402
 from gr_uwspr_amd import dist as D  # noqa: E402
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-B, NB, NL = 256, 5, 3
+B, NB = 256, 5
+NL = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = torch.device("cuda", 0)
 N = G.native
 streams = [torch.cuda.Stream(device=dev) for _ in range(NL)]
